@@ -1,0 +1,20 @@
+"""CPU oracle for the grid-sweep hot path -- TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and the ``cpu_baseline`` leg of ``bench.py``
+may import this package; the product (``inflatox_amd``) never does.
+
+Pieces:
+  * ``sweep_oracle.c``  C restatement of the reference's native sweep (see its header).
+  * ``model_c.py``      restatement of the reference transpiler's C back-end: emits the
+                        per-model C file with the reference's ABI and builds it with gcc
+                        using the reference's compiler flags.
+  * ``cpu_oracle.py``   ctypes bindings for the two above.
+
+Parity status: pinned by the reference's known-answer test (tests/test_doc.py:50-51) and by
+golden vectors produced from the reference's own Python stages (tests/golden/); the Rust
+half of the reference cannot be built in the authoring container (no rustc/cargo), see
+DESIGN.md "Oracle".
+"""
+
+from .cpu_oracle import OracleModel, build_sweep_library, OP  # noqa: F401
+from .model_c import emit_c_source, compile_c_model  # noqa: F401

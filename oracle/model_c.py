@@ -1,0 +1,168 @@
+"""Restatement of the reference transpiler's C back-end -- TEST INFRASTRUCTURE ONLY.
+
+Follows (citations relative to /root/reference):
+  * printer rules           python/inflatox/compiler.py:37-120   (field -> x[i], tangent -> xdot[i],
+                            every other symbol -> args[k], k = order of first appearance)
+  * function emission       python/inflatox/compiler.py:398-472  (optional per-function sympy.cse)
+  * file layout & globals   python/inflatox/compiler.py:474-566  (V, inner_prod, v{a}{b}, v, w1,
+                            grad_norm_squared, eom*, then VERSION/DIM/N_PARAMETERS/MODEL_NAME/USE_GSL)
+  * compiler flags          python/inflatox/compiler.py:299-310  (no fast-math!)
+
+The reference shells out to ``zig cc`` (clang); zig is absent here, so the host C compiler
+(``gcc``, or ``clang`` if asked) is used with the same flag list.
+"""
+
+from __future__ import annotations
+
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import sympy
+from sympy.printing.c import C99CodePrinter
+
+ABI_VERSION = (5, 0, 0)  # python/inflatox/version.py:22
+
+REFERENCE_FLAGS = [
+    "-O3",
+    "-Wall",
+    "-Werror",
+    "-fpic",
+    "-lm",
+    "-march=native",
+    "-shared",
+    "-std=c17",
+    "-fno-math-errno",
+    "-fno-signed-zeros",
+]
+
+
+class _OraclePrinter(C99CodePrinter):
+    """C99 printer with the reference's symbol-mapping rules."""
+
+    def __init__(self, fields, tangents):
+        super().__init__()
+        base = super()._print_Symbol
+        self.slots = {base(s): f"x[{i}]" for i, s in enumerate(fields)}
+        self.slots.update({base(s): f"xdot[{i}]" for i, s in enumerate(tangents)})
+        self.n_coord_slots = len(self.slots)
+        self.params = {}
+
+    def _print_Symbol(self, expr):
+        if expr.is_number:
+            return expr.evalf(self._settings["precision"])
+        name = super()._print_Symbol(expr)
+        if name.startswith("cse"):
+            return name
+        if name in self.slots:
+            return self.slots[name]
+        if name not in self.params:
+            self.params[name] = f"args[{len(self.params)}]"
+        return self.params[name]
+
+
+def _cse_symbols(limit):
+    k = 0
+    while k <= limit:
+        yield sympy.Symbol(f"cse{k}")
+        k += 1
+    raise RuntimeError("Maximum number of common subexpressions reached!")
+
+
+def _scalar_fn(sig, expr, pr, cse, max_cses):
+    lines = [sig + "{"]
+    if cse:
+        repl, red = sympy.cse(expr, symbols=_cse_symbols(max_cses), order="none", list=False)
+        for s, d in repl:
+            lines.append(f"    const double {pr.doprint(s)} = {pr.doprint(d)};")
+        lines.append(f"    return {pr.doprint(red)};")
+    else:
+        lines.append(f"    return {pr.doprint(expr)};")
+    lines.append("}\n")
+    return "\n".join(lines) + "\n"
+
+
+def _vector_fn(sig, vec, pr, cse, max_cses):
+    lines = [sig + "{"]
+    comps = list(vec)
+    if cse:
+        repl, comps = sympy.cse(list(vec), symbols=_cse_symbols(max_cses), list=True)
+        for s, d in repl:
+            lines.append(f"    const double {pr.doprint(s)} = {pr.doprint(d)};")
+    for i, c in enumerate(comps):
+        lines.append(f"    v_out[{i}] = {pr.doprint(c)};")
+    lines.append("    return;\n}\n")
+    return "\n".join(lines) + "\n"
+
+
+def _inner_prod_fn(metric, dim, pr, cse, max_cses):
+    lines = ["double inner_prod(const double x[], const double args[], const double v1[], const double v2[]){"]
+    flat = [metric[i][j] for i in range(dim) for j in range(dim)]
+    if cse:
+        repl, flat = sympy.cse(flat, symbols=_cse_symbols(max_cses), list=True)
+        for s, d in repl:
+            lines.append(f"    const double {pr.doprint(s)} = {pr.doprint(d)};")
+    ret = "0.0"
+    for i in range(dim):
+        # NB: the reference's running index (compiler.py:461-464) is n = dim*i, then n += j
+        # cumulatively, i.e. entries (i*dim + 0), (i*dim + 0 + 1), (i*dim + 0 + 1 + 2) ...;
+        # for dim == 2 that is the plain row-major index, which is the only case on this path.
+        n = dim * i
+        for j in range(dim):
+            n += j
+            txt = pr.doprint(flat[n])
+            if txt in ("0", "0.0"):
+                continue
+            lines.append(f"    const double g{i}{j} = {txt};")
+            ret += f" + (g{i}{j} * v1[{i}] * v2[{j}])"
+    lines.append(f"    return {ret};")
+    lines.append("}\n")
+    return "\n".join(lines) + "\n"
+
+
+def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool = True):
+    """Return ``(c_source, symbol_dictionary)`` for an InflationModel-like object."""
+    pr = _OraclePrinter(model.coordinates, model.coordinate_tangents)
+    dim = model.dim
+    body = _scalar_fn("double V(const double x[], const double args[])", model.potential, pr, cse, max_cses)
+    body += _inner_prod_fn(model.metric, dim, pr, cse, max_cses)
+    for a in range(dim):
+        for b in range(dim):
+            body += _scalar_fn(f"double v{a}{b}(const double x[], const double args[])", model.hesse_cmp[a][b], pr, cse, max_cses)
+    for k in range(dim):
+        nm = "v" if k == 0 else f"w{k}"
+        body += _vector_fn(f"void {nm}(const double x[], const double args[], double v_out[])", model.basis[k], pr, cse, max_cses)
+    body += _scalar_fn("double grad_norm_squared(const double x[], const double args[])", model.gradient_square, pr, cse, max_cses)
+    if with_eom and getattr(model, "eom_fields", None) is not None:
+        for a in range(dim):
+            body += _scalar_fn(
+                f"double eom{a}(const double x[], const double xdot[], const double args[])", model.eom_fields[a], pr, cse, max_cses
+            )
+        body += _scalar_fn("double eomh(const double x[], const double xdot[], const double args[])", model.eom_h, pr, cse, max_cses)
+        body += _scalar_fn("double eomhdot(const double x[], const double xdot[], const double args[])", model.eom_hdot, pr, cse, max_cses)
+    head = "#include <math.h>\n#include <stdint.h>\n"
+    head += f"const uint16_t VERSION[3] = {{{ABI_VERSION[0]},{ABI_VERSION[1]},{ABI_VERSION[2]}}};\n"
+    head += f"const uint32_t DIM = {dim};\n"
+    head += f"const uint32_t N_PARAMETERS = {len(pr.params)};\n"
+    head += f'char *const MODEL_NAME = "{model.model_name}";\n'
+    head += "const char USE_GSL = 0;\n\n"
+    symdict = {k: v for k, v in pr.slots.items() if v.startswith("x[")}
+    symdict.update(pr.params)
+    return head + body, symdict
+
+
+def compile_c_model(c_source: str, out_dir: str | None = None, cc: str = "gcc", flags=None) -> str:
+    """Compile a generated C file with the reference's flag list; returns the .so path."""
+    out_dir = out_dir or os.path.join(tempfile.gettempdir(), "inflx_oracle_models")
+    os.makedirs(out_dir, exist_ok=True)
+    tag = hashlib.sha1((cc + c_source).encode()).hexdigest()[:16]
+    so = os.path.join(out_dir, f"liboracle_model_{tag}.so")
+    if not os.path.exists(so):
+        src = os.path.join(out_dir, f"oracle_model_{tag}.c")
+        with open(src, "w") as fh:
+            fh.write(c_source)
+        cmd = [cc, "-o", so + ".tmp", src, *(flags or REFERENCE_FLAGS)]
+        subprocess.run(cmd, check=True)
+        os.replace(so + ".tmp", so)
+    return so

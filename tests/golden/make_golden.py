@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ from the reference's own Python stages.
+
+Run ONLY in the authoring container (needs /root/reference; the GPU box has neither the
+reference nor any need for this script -- it consumes the committed .npz/.json fixtures).
+
+Pipeline:
+  1. import the reference's ``inflatox`` Python package from /root/reference/python with three
+     absent modules stubbed in ``sys.modules`` (``interruptingcow`` as a real SIGALRM timer,
+     ``inflatox.version``, ``inflatox.libinflx_rs`` as names that raise when called);
+  2. run the reference's ``InflationModelBuilder.new(...).build(...)`` and
+     ``Compiler(...)._generate_c_file()`` on the model definitions of
+     ``inflatox_amd/example_models.py`` (the models of the reference's README/tests);
+  3. compile the reference-emitted C with gcc and the reference's flag list (into a temp dir);
+  4. evaluate it through oracle/sweep_oracle.c (the C restatement of the Rust sweep) on small
+     grids, adversarial points included, and store numbers only:
+        tests/golden/<model>.npz   args, extent, N0, N1, out (N0,N1,6), raw (N0,N1,5) + extras
+        tests/golden/symbols.json  per-model symbol tables, N_PARAMETERS, printer strings
+Nothing of the reference (source, generated C, binaries) is written into the repository.
+"""
+
+from __future__ import annotations
+
+import contextlib
+import json
+import os
+import signal
+import sys
+import tempfile
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF_PY = "/root/reference/python"
+sys.path.insert(0, ROOT)
+
+
+def _install_stubs():
+    # interruptingcow.timeout: faithful ITIMER_REAL/SIGALRM context manager
+    cow = types.ModuleType("interruptingcow")
+
+    @contextlib.contextmanager
+    def timeout(seconds, exception=RuntimeError):
+        def handler(signum, frame):
+            raise exception()
+
+        old = signal.signal(signal.SIGALRM, handler)
+        signal.setitimer(signal.ITIMER_REAL, seconds)
+        try:
+            yield
+        finally:
+            signal.setitimer(signal.ITIMER_REAL, 0)
+            signal.signal(signal.SIGALRM, old)
+
+    cow.timeout = timeout
+    sys.modules["interruptingcow"] = cow
+
+    pkg = types.ModuleType("inflatox")
+    pkg.__path__ = [os.path.join(REF_PY, "inflatox")]
+    sys.modules["inflatox"] = pkg
+    ver = types.ModuleType("inflatox.version")
+    ver.__version__ = "0.10.0"
+    ver.__abi_version__ = "5.0.0"
+    sys.modules["inflatox.version"] = ver
+    rs = types.ModuleType("inflatox.libinflx_rs")
+
+    def _absent(*a, **k):
+        raise RuntimeError("libinflx_rs (Rust) is not built in this container")
+
+    for nm in ("log_info", "log_warn", "open_inflx_dylib", "complete_analysis"):
+        setattr(rs, nm, _absent)
+    rs.log_warn = lambda msg: print(f"[ref warn] {msg}", file=sys.stderr)
+    rs.log_info = lambda msg: print(f"[ref info] {msg}", file=sys.stderr)
+    sys.modules["inflatox.libinflx_rs"] = rs
+
+
+def load_reference():
+    _install_stubs()
+    import importlib
+
+    symbolic = importlib.import_module("inflatox.symbolic")
+    compiler = importlib.import_module("inflatox.compiler")
+    return symbolic, compiler
+
+
+# grids: (tag, N0, N1, extent or None for the spec's default)
+GRIDS = {
+    "hyperbolic": [("g16", 16, 16, None), ("g64", 64, 48, None), ("ragged", 7, 13, (-0.9, 1.3, 0.1, 2.0))],
+    "doc": [("g16", 16, 16, None), ("g64", 64, 48, None), ("neg", 9, 11, (-1.0, 1.0, -2.0, 2.0))],
+    "angular": [("g16", 16, 16, None), ("g64", 64, 48, None), ("inner", 12, 10, (-0.6, 0.6, -0.6, 0.6))],
+    "egno": [("g16", 16, 16, None), ("g64", 64, 48, None)],
+    "d5": [("g16", 16, 16, None), ("g64", 64, 48, None)],
+}
+
+
+def main(models):
+    import joblib
+
+    from inflatox_amd import example_models
+    from oracle import OP, OracleModel
+    from oracle.model_c import REFERENCE_FLAGS
+
+    symbolic, compiler = load_reference()
+    sym_path = os.path.join(HERE, "symbols.json")
+    symbols = json.load(open(sym_path)) if os.path.exists(sym_path) else {}
+    tmp = tempfile.mkdtemp(prefix="inflx_golden_")
+
+    for name in models:
+        spec = example_models.get(name)
+        print(f"== {name}: reference symbolic stage", flush=True)
+        with joblib.parallel_backend("sequential"):
+            builder = symbolic.InflationModelBuilder.new(
+                spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
+            )
+            model = builder.build(spec.guesses)
+        c_path = os.path.join(tmp, f"{name}.c")
+        comp = compiler.Compiler(model, output_path=c_path, silent=True, **spec.compiler_kwargs)
+        with contextlib.redirect_stdout(open(os.devnull, "w")):
+            comp._generate_c_file()
+        so_path = os.path.join(tmp, f"{name}.so")
+        import subprocess
+
+        subprocess.run(["gcc", "-o", so_path, c_path, *REFERENCE_FLAGS], check=True)
+        om = OracleModel(so_path)
+        symbols[name] = {
+            "symbol_dictionary": comp.symbol_dict,
+            "n_parameters": int(om.n_parameters),
+            "n_fields": int(om.n_fields),
+            "arg_names": spec.arg_names,
+            "c_bytes": os.path.getsize(c_path),
+        }
+        assert om.n_parameters == len(spec.args), (om.n_parameters, spec.args)
+        out = {"args": spec.args}
+        for tag, n0, n1, ext in GRIDS[name]:
+            ext = np.array(ext if ext is not None else spec.extent, dtype=np.float64)
+            out[f"{tag}_extent"] = ext
+            out[f"{tag}_shape"] = np.array([n0, n1])
+            out[f"{tag}_out"] = om.grid_sweep(OP.COMPLETE, spec.args, ext, n0, n1)
+            out[f"{tag}_raw"] = om.grid_sweep(OP.RAW, spec.args, ext, n0, n1)
+            out[f"{tag}_consistency"] = om.grid_sweep(OP.CONSISTENCY, spec.args, ext, n0, n1)
+            out[f"{tag}_rapidturn"] = om.grid_sweep(OP.RAPIDTURN, spec.args, ext, n0, n1)
+            out[f"{tag}_epsilon_v"] = om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1)
+        if name == "doc":
+            # the reference's only known-answer test on this path: tests/test_doc.py:50-51
+            x = np.array([2.0, -2.0])
+            out["kat_x"] = x
+            out["kat_V"] = np.array(om.potential(x, spec.args))
+            out["kat_H"] = om.hesse(x, spec.args)
+            assert out["kat_V"] == 1.9166666666666667
+            assert np.allclose(out["kat_H"], np.array([[0.41206897, -1.05517241], [-1.05517241, -0.07873563]]))
+            full = om.grid_sweep(OP.COMPLETE, spec.args, spec.extent, 1000, 1000, threads=8)
+            assert np.nanmax(full[:, :, 0]) <= 1  # tests/test_doc.py:58
+            out["full1000_nanmax_consistency"] = np.array(np.nanmax(full[:, :, 0]))
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        print(f"   wrote {name}.npz; symbols = {comp.symbol_dict}", flush=True)
+        om.close()
+
+    # printer known-answer strings (reference tests/test_compiler.py:40-53 hold the expected text)
+    import sympy
+
+    x, y, a, b, xd, yd = sympy.symbols("x y a b \\dot{{x}} \\dot{{y}}")
+    pr = compiler.CInflatoxPrinter([x, y], [xd, yd])
+    symbols["_printer_kat"] = {
+        "x": pr._print_Symbol(x),
+        "y": pr._print_Symbol(y),
+        "a": pr._print_Symbol(a),
+        "b": pr._print_Symbol(b),
+        "xdot": pr._print_Symbol(xd),
+        "ydot": pr._print_Symbol(yd),
+        "x**2 + y": pr.doprint(x**2 + y),
+        "x*y": pr.doprint(x * y),
+        "sqrt(a)*y": pr.doprint(sympy.sqrt(a) * y),
+        "sin(x)": pr.doprint(sympy.sin(x)),
+    }
+    json.dump(symbols, open(sym_path, "w"), indent=1, ensure_ascii=False, sort_keys=True)
+    print("wrote symbols.json")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1:] or list(GRIDS))
