@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""Headline benchmark: grid-points/s of the complete_analysis sweep (BASELINE.json `metric`).
+
+  python bench.py [--gpus N --steps K --warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path: ONE complete_analysis sweep of the BASELINE configs[1]
+workload -- README hyperbolic model, args [m, phi0, L] = [1, 1, 1], extent (-1, 1, -1, 1),
+8192 x 8192 field grid, six f64 per point (48 B) written to a device-resident (N0, N1, 6) array.
+Multi-GPU (weak scaling, BASELINE configs[4] style): the outer *parameter* axis is sharded, every
+rank sweeps the full grid for its own parameter row (L differs per rank); results stay on the
+rank's GPU (no data-path collective: the rows are independent; the only collectives are the timing
+barrier and the MAX over ranks).
+
+Timed region: inputs (parameters, code object) resident on the device, result left in HBM.
+PyTorch provides the device buffer, the stream and torch.distributed only; every launch goes
+through the C ABI (libinflx_hip.so).
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
+
+
+def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
+    """Oracle (C restatement of the reference's rayon sweep: five indirect calls per point into the
+    gcc -O3 model object + ops::complete_analysis) on all host cores, bounded sample."""
+    import numpy as np
+
+    import oracle
+    from inflatox_amd import example_models, workloads
+
+    spec = example_models.get(model_name)
+    src, _ = oracle.emit_c_source(workloads.model_for(model_name), **spec.compiler_kwargs)
+    om = oracle.OracleModel(oracle.compile_c_model(src))
+    cores = os.cpu_count() or 1
+    n = 1024
+    t0 = time.perf_counter()
+    om.grid_sweep(oracle.OP.COMPLETE, args, extent, n, n, threads=cores)  # warm-up + calibration
+    t_cal = time.perf_counter() - t0
+    # choose the sample so that one pass takes about budget/3 seconds
+    scale = max(1.0, (budget_s / 3.0) / max(t_cal, 1e-3))
+    n = int(min(8192, 1024 * np.sqrt(scale)) // 64 * 64)
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        om.grid_sweep(oracle.OP.COMPLETE, args, extent, n, n, threads=cores)
+        best = min(best, time.perf_counter() - t0)
+    return {
+        "value": n * n / best,
+        "unit": "grid-points/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{model_name} {n}x{n} sub-grid of the same extent, best of 3, {cores} threads, gcc -O3 model object + C restatement of the Rust sweep",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--model", default="hyperbolic")
+    ap.add_argument("--n", type=int, default=8192, help="grid points per axis")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    opt = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != opt.gpus:
+        raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {opt.gpus}")
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from inflatox_amd import _native, workloads
+
+    spec, art = workloads.artifact_for(opt.model)
+    lib = _native.InflatoxDevLib(art.shared_object_path, device=local_rank)
+
+    N0 = N1 = opt.n
+    # outer parameter axis: one row per rank; rank r gets the r-th value of the last parameter
+    # scaled over [1, 2) (for the hyperbolic model that is L, as in BASELINE configs[4])
+    args = np.array(spec.args, dtype=np.float64)
+    if world > 1:
+        args[-1] = args[-1] * (1.0 + rank / world)
+    out = torch.empty((N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
+    stream = torch.cuda.current_stream().cuda_stream
+    nbytes = out.numel() * 8
+
+    def step():
+        lib.sweep_device(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream)
+
+    for _ in range(opt.warmup):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(opt.steps):
+        step()
+    torch.cuda.synchronize()
+    if distributed:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # dominant kernel, measured live with HIP events on the launch stream
+    ms_kernel = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(5, opt.steps))
+    points = N0 * N1
+    achieved = BYTES_PER_POINT * points / (ms_kernel * 1e-3) / 1e9
+
+    if rank == 0:
+        line = {
+            "metric": "grid-points/sec on complete_analysis sweep",
+            "value": world * points * opt.steps / elapsed,
+            "unit": "grid-points/s",
+            "n_gpus": world,
+            "steps": opt.steps,
+            "warmup": opt.warmup,
+            "ms_per_step": elapsed / opt.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{opt.model} model, {N0}x{N1} field grid, args {spec.args.tolist()}, extent {list(spec.extent)}, complete_analysis (6 f64/point, AoS), device-resident result",
+                "parameter_rows_per_gpu": 1,
+                "parallelism": f"parameter-axis x{world}" if world > 1 else "single GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBPS,
+                "traffic": None,
+                "kernel": "inflx_sweep_rows_complete" if lib.stage_info["out_mask"] & 2 == 0 else "inflx_sweep_tile_complete",
+                "kernel_ms": ms_kernel,
+                "algorithmic_bytes_per_launch": BYTES_PER_POINT * points,
+            },
+        }
+        if world == 1 and not opt.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(opt.model, spec.args, spec.extent)
+        print(json.dumps(line), flush=True)
+    if distributed:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+/*
+ * inflx_hip.h -- C ABI of libinflx_hip.so, the MI355X-native replacement for the grid-sweep
+ * entry points of the reference's native module `libinflx_rs`.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the reference
+ * repository).  Signatures use plain pointers and sizes only; the caller owns every host buffer
+ * (`p`, `out`, `start_stop`, `x`), the library owns the device memory, stream and code object
+ * held by an `inflx_model`.  All functions return an `inflx_status`; on failure
+ * `inflx_last_error()` returns a thread-local message.  The mapping to the Python exception
+ * classes the reference raises (src/err.rs:63-74) is given with each status.
+ *
+ * A "model artefact" is the per-model gfx950 code object written by inflatox_amd.Compiler -- the
+ * counterpart of the per-model dylib the reference compiles with zig cc
+ * (python/inflatox/compiler.py:568-598) and opens with libloading (src/dylib.rs:67-161).
+ */
+#ifndef INFLX_HIP_H
+#define INFLX_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct inflx_model inflx_model;
+
+typedef enum inflx_status {
+  INFLX_OK = 0,
+  INFLX_ERR_IO = 1,      /* artefact cannot be opened              -> IOError      (err.rs:65)    */
+  INFLX_ERR_SYMBOL = 2,  /* artefact lacks a required symbol       -> SystemError  (err.rs:66-69) */
+  INFLX_ERR_VERSION = 3, /* artefact built for another ABI version -> SystemError  (err.rs:70)    */
+  INFLX_ERR_SHAPE = 4,   /* array shape / parameter count mismatch -> Exception    (err.rs:71)    */
+  INFLX_ERR_DEVICE = 5,  /* HIP runtime failure (no counterpart)   -> SystemError                 */
+  INFLX_ERR_ARG = 6      /* invalid argument (NULL, bad enum)      -> ValueError; the reference
+                            panics on the analogous conditions (anguelova.rs:473,501)             */
+} inflx_status;
+
+/* per-point operation selector; numbering shared with the kernels (csrc/inflx_kernel_abi.h) */
+typedef enum inflx_op {
+  INFLX_SWEEP_COMPLETE = 0,    /* ops::complete_analysis          anguelova.rs:103-135, 6 f64/point */
+  INFLX_SWEEP_CONSISTENCY = 1, /* ops::consistency_only           anguelova.rs:157-163, 1 f64/point */
+  INFLX_SWEEP_RAPIDTURN = 2,   /* ops::consistency_rapidturn_only anguelova.rs:143-154, 1 f64/point */
+  INFLX_SWEEP_EPSILON_V = 3,   /* ops::epsilon_v_only             anguelova.rs:138-140, 1 f64/point */
+  INFLX_SWEEP_RAW = 4          /* V,v00,v10,v11,|dV|^2 (diagnostic, 5 f64/point; what Potential /
+                                  Hesse2D return, hesse_bindings.rs:52-57,106-110,213-231)          */
+} inflx_op;
+
+typedef enum inflx_layout {
+  INFLX_AOS = 0, /* [P][rows][N1][K] -- the reference's (N0,N1,6) array (consistency_conditions.py:290) */
+  INFLX_SOA = 1  /* [P][K][rows][N1] -- K contiguous planes */
+} inflx_layout;
+
+/* thread-local description of the last failure on the calling thread */
+const char* inflx_last_error(void);
+
+/* number of visible HIP devices */
+int inflx_device_count(int* count);
+
+/*
+ * Open a model artefact on `device` -- replaces InflatoxDylib::open (src/dylib.rs:67-161) as
+ * reached from open_inflx_dylib (src/lib.rs:108-115): loads the code object, checks VERSION
+ * (major.minor against 5.0, src/inflatox_version.rs:48-53, src/lib.rs:50), reads DIM,
+ * N_PARAMETERS, MODEL_NAME and resolves the sweep kernels.
+ */
+int inflx_open(const char* artefact_path, int device, inflx_model** out);
+void inflx_close(inflx_model* model);
+
+/* InflatoxDylib::{n_fields,n_pars,name} (src/dylib.rs:285-301) */
+uint32_t inflx_n_fields(const inflx_model* model);
+uint32_t inflx_n_parameters(const inflx_model* model);
+const char* inflx_model_name(const inflx_model* model);
+int inflx_device_of(const inflx_model* model);
+/* staging facts of the loaded kernels: exported uniform/row/column values and the axis mask of the
+ * five model values (bit0 = x[0], bit1 = x[1]) */
+int inflx_stage_info(const inflx_model* model, uint32_t* n_uniform, uint32_t* n_row, uint32_t* n_col, uint32_t* out_mask);
+
+/*
+ * Drop-ins for the #[pyfunction]s of src/anguelova.rs.  Host buffers, C-contiguous f64:
+ *   p           (n_p,)           model parameters
+ *   start_stop  (2,2) row-major  [[x0_start,x0_stop],[x1_start,x1_stop]]  (src/lib.rs:117-139)
+ *   out         (N0,N1,6) for complete_analysis, (N0,N1) for the single-quantity sweeps
+ * `progress` != 0 prints the reference's start/finish lines to stderr; `threads` is accepted for
+ * signature compatibility and ignored (the sweep runs on the GPU).
+ */
+int inflx_complete_analysis(inflx_model* model, const double* p, size_t n_p, double* out, const double* start_stop,
+                            size_t N0, size_t N1, int progress, size_t threads); /* anguelova.rs:458-550 */
+int inflx_consistency_only(inflx_model* model, const double* p, size_t n_p, double* out, const double* start_stop,
+                           size_t N0, size_t N1, int progress, size_t threads); /* anguelova.rs:176-264 */
+int inflx_consistency_rapidturn_only(inflx_model* model, const double* p, size_t n_p, double* out,
+                                     const double* start_stop, size_t N0, size_t N1, int progress,
+                                     size_t threads); /* anguelova.rs:267-356 */
+int inflx_epsilon_v_only(inflx_model* model, const double* p, size_t n_p, double* out, const double* start_stop,
+                         size_t N0, size_t N1, int progress, size_t threads); /* anguelova.rs:359-447 */
+
+/* on-trajectory variants (src/anguelova.rs:633-977): x is (n,2), out is (n,K) */
+int inflx_sweep_on_trajectory(inflx_model* model, int op, const double* p, size_t n_p, const double* x, size_t n,
+                              double* out, int progress, size_t threads);
+
+/*
+ * Generalised sweep, host result.  P parameter rows (p is (P,n_p)), grid rows
+ * [row_begin,row_begin+row_count) of the N0 x N1 grid, result written to the host buffer `out`
+ * of P*row_count*N1*K doubles in `layout`.  Rows are processed in device-sized chunks and copied
+ * back while the next chunk computes.
+ */
+int inflx_sweep_host(inflx_model* model, int op, const double* p, size_t P, size_t n_p, double* out,
+                     const double* start_stop, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout);
+
+/*
+ * Generalised sweep, device-resident result: `d_out` is device memory of at least
+ * P*row_count*N1*K*8 bytes on the model's device (`d_out_bytes` is checked); the kernel is
+ * enqueued on `stream` (a hipStream_t; NULL = the model's own stream) and the call returns without
+ * synchronising.  This is what the multi-GPU sharding and the benchmark use.
+ */
+int inflx_sweep_device(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
+                       size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
+                       size_t row_count, int layout, void* stream);
+
+/* As inflx_sweep_device, `repeats` times back to back between two HIP events recorded on the
+ * launch stream; returns the mean kernel-launch duration in milliseconds (synchronises). */
+int inflx_sweep_device_timed(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
+                             size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
+                             size_t row_count, int layout, void* stream, int repeats, float* ms_per_launch);
+
+/* wait for everything enqueued on the model's own stream */
+int inflx_synchronize(inflx_model* model);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* INFLX_HIP_H */

@@ -1,0 +1,265 @@
+"""ctypes binding of ``libinflx_hip.so`` (C ABI: ``include/inflx_hip.h``).
+
+This is the stand-in for the reference's PyO3 module ``libinflx_rs`` on the sweep path
+(src/lib.rs:68-92).  There is deliberately no fallback: if the shared library is missing, or
+no HIP device is usable, every call raises -- the product never computes on the CPU.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_REPO = os.path.dirname(_PKG)
+LIB_PATH = os.path.join(_PKG, "libinflx_hip.so")
+
+OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG = range(7)
+
+OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
+OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5}
+LAYOUT_AOS, LAYOUT_SOA = 0, 1
+
+_DP = C.POINTER(C.c_double)
+_SIZE = C.c_size_t
+
+# name -> (restype, argtypes); one entry per symbol declared in include/inflx_hip.h
+SIGNATURES = {
+    "inflx_last_error": (C.c_char_p, []),
+    "inflx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+    "inflx_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "inflx_close": (None, [C.c_void_p]),
+    "inflx_n_fields": (C.c_uint32, [C.c_void_p]),
+    "inflx_n_parameters": (C.c_uint32, [C.c_void_p]),
+    "inflx_model_name": (C.c_char_p, [C.c_void_p]),
+    "inflx_device_of": (C.c_int, [C.c_void_p]),
+    "inflx_stage_info": (C.c_int, [C.c_void_p] + [C.POINTER(C.c_uint32)] * 4),
+    "inflx_complete_analysis": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_consistency_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_consistency_rapidturn_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_epsilon_v_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_sweep_on_trajectory": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _DP, _SIZE, _DP, C.c_int, _SIZE]),
+    "inflx_sweep_host": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int]),
+    "inflx_sweep_device": (
+        C.c_int,
+        [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p],
+    ),
+    "inflx_sweep_device_timed": (
+        C.c_int,
+        [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p, C.c_int, C.POINTER(C.c_float)],
+    ),
+    "inflx_synchronize": (C.c_int, [C.c_void_p]),
+}
+
+_lib = None
+
+
+def build_library(force: bool = False) -> str:
+    """Compile ``csrc/inflx_hip.cpp`` into ``libinflx_hip.so`` in-tree (hipcc, host code only)."""
+    src = os.path.join(_PKG, "csrc", "inflx_hip.cpp")
+    deps = [src, os.path.join(_PKG, "csrc", "inflx_kernel_abi.h"), os.path.join(_REPO, "include", "inflx_hip.h")]
+    stale = force or not os.path.exists(LIB_PATH) or any(os.path.getmtime(d) > os.path.getmtime(LIB_PATH) for d in deps)
+    if stale:
+        from .compiler import hipcc_path
+
+        cmd = [
+            hipcc_path(),
+            "-O2",
+            "-fPIC",
+            "-shared",
+            "-std=c++17",
+            "-Wall",
+            "-Wextra",
+            f"-I{os.path.join(_REPO, 'include')}",
+            f"-I{os.path.join(_PKG, 'csrc')}",
+            src,
+            "-o",
+            LIB_PATH + ".tmp",
+        ]
+        subprocess.run(cmd, check=True)
+        os.replace(LIB_PATH + ".tmp", LIB_PATH)
+    return LIB_PATH
+
+
+def load_library():
+    """Load ``libinflx_hip.so`` and declare every entry point; raises if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(the sweep has no CPU fallback)"
+            )
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+class InflatoxShapeError(Exception):
+    """Counterpart of LibInflxRsErr::Shape, which PyO3 raises as a plain Exception (err.rs:71)."""
+
+
+def _raise(rc: int):
+    msg = load_library().inflx_last_error().decode("utf-8", "replace")
+    if rc == ERR_IO:
+        raise IOError(msg)
+    if rc in (ERR_SYMBOL, ERR_VERSION, ERR_DEVICE):
+        raise SystemError(msg)
+    if rc == ERR_SHAPE:
+        raise InflatoxShapeError(msg)
+    raise ValueError(msg)
+
+
+def _check(rc: int):
+    if rc != OK:
+        _raise(rc)
+
+
+def _f64(a, name: str) -> np.ndarray:
+    """C-contiguous float64 view/copy.  (The reference panics on non-contiguous input,
+    anguelova.rs:473; here it is made contiguous instead.)"""
+    try:
+        return np.ascontiguousarray(a, dtype=np.float64)
+    except (TypeError, ValueError) as exc:
+        raise ValueError(f"{name} must be convertible to a float64 array") from exc
+
+
+def _ptr(a: np.ndarray):
+    return a.ctypes.data_as(_DP)
+
+
+def device_count() -> int:
+    n = C.c_int(0)
+    rc = load_library().inflx_device_count(C.byref(n))
+    return n.value if rc == OK else 0
+
+
+class InflatoxDevLib:
+    """An opened model artefact on one HIP device (counterpart of ``InflatoxPyDyLib``, lib.rs:104)."""
+
+    def __init__(self, artefact_path: str, device: int = 0):
+        lib = load_library()
+        handle = C.c_void_p()
+        _check(lib.inflx_open(os.fsencode(artefact_path), int(device), C.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.path = artefact_path
+        self.device = int(device)
+        self.n_fields = int(lib.inflx_n_fields(handle))
+        self.n_parameters = int(lib.inflx_n_parameters(handle))
+        self.name = lib.inflx_model_name(handle).decode("utf-8", "replace")
+        vals = [C.c_uint32(0) for _ in range(4)]
+        _check(lib.inflx_stage_info(handle, *[C.byref(v) for v in vals]))
+        self.stage_info = dict(zip(("n_uniform", "n_row", "n_col", "out_mask"), (v.value for v in vals)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.inflx_close(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- drop-ins for the #[pyfunction]s of src/anguelova.rs ---------------------------------
+    def _grid(self, fn, p, out, start_stop, progress, threads, last_axis):
+        p = _f64(p, "p").reshape(-1)
+        ss = _f64(start_stop, "start_stop")
+        if ss.shape != (2, 2):  # convert_start_stop, src/lib.rs:117-139
+            raise InflatoxShapeError(f"start_stop array should have 2 rows and as many columns as there are fields (got {ss.shape})")
+        if out.dtype != np.float64 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("output array must be a writeable C-contiguous float64 array")
+        if last_axis is not None and (out.ndim != 3 or out.shape[2] != last_axis):
+            raise InflatoxShapeError(f"Output array should be 3D. Last axis must have lenght {last_axis} (got {out.shape})")
+        if last_axis is None and out.ndim != 2:
+            raise InflatoxShapeError(f"Output array should be 2D (got {out.shape})")
+        _check(fn(self._h, _ptr(p), p.size, _ptr(out), _ptr(ss), out.shape[0], out.shape[1], int(bool(progress)), int(threads)))
+
+    def complete_analysis(self, p, out, start_stop, progress=False, threads=0):
+        """libinflx_rs.complete_analysis(lib, p, out, start_stop, progress, threads), anguelova.rs:458."""
+        self._grid(self._lib.inflx_complete_analysis, p, out, start_stop, progress, threads, 6)
+
+    def consistency_only(self, p, out, start_stop, progress=False, threads=0):
+        self._grid(self._lib.inflx_consistency_only, p, out, start_stop, progress, threads, None)
+
+    def consistency_rapidturn_only(self, p, out, start_stop, progress=False, threads=0):
+        self._grid(self._lib.inflx_consistency_rapidturn_only, p, out, start_stop, progress, threads, None)
+
+    def epsilon_v_only(self, p, out, start_stop, progress=False, threads=0):
+        self._grid(self._lib.inflx_epsilon_v_only, p, out, start_stop, progress, threads, None)
+
+    def sweep_on_trajectory(self, op, p, x, progress=False, threads=0) -> np.ndarray:
+        p = _f64(p, "p").reshape(-1)
+        x = _f64(x, "x")
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise InflatoxShapeError(f"trajectory array should have shape (n,2) (got {x.shape})")
+        k = OP_WIDTH[op]
+        out = np.zeros((x.shape[0], k) if k > 1 else (x.shape[0],))
+        _check(self._lib.inflx_sweep_on_trajectory(self._h, op, _ptr(p), p.size, _ptr(x), x.shape[0], _ptr(out), int(bool(progress)), int(threads)))
+        return out
+
+    # ---- generalised sweeps -------------------------------------------------------------------
+    def sweep_host(self, op, p, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS) -> np.ndarray:
+        """P parameter rows x rows [row_begin,row_begin+row_count) of the grid -> host ndarray."""
+        p = _f64(p, "p")
+        single = p.ndim == 1
+        p2 = p.reshape(1, -1) if single else p
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        row_count = N0 - row_begin if row_count is None else row_count
+        P, k = p2.shape[0], OP_WIDTH[op]
+        if k == 1:
+            shape = (P, row_count, N1)
+        elif layout == LAYOUT_AOS:
+            shape = (P, row_count, N1, k)
+        else:
+            shape = (P, k, row_count, N1)
+        out = np.empty(shape)
+        _check(self._lib.inflx_sweep_host(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, layout))
+        return out[0] if single else out
+
+    def sweep_device(self, op, p, d_out_ptr: int, d_out_bytes: int, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0):
+        """Enqueue a sweep whose result stays in device memory at ``d_out_ptr`` (no sync)."""
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        row_count = N0 - row_begin if row_count is None else row_count
+        _check(
+            self._lib.inflx_sweep_device(
+                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream)
+            )
+        )
+
+    def sweep_device_timed(self, op, p, d_out_ptr, d_out_bytes, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, repeats: int = 10) -> float:
+        """Mean launch duration (ms) over ``repeats`` launches, HIP events on the launch stream."""
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        row_count = N0 - row_begin if row_count is None else row_count
+        ms = C.c_float(0.0)
+        _check(
+            self._lib.inflx_sweep_device_timed(
+                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, C.byref(ms)
+            )
+        )
+        return float(ms.value)
+
+    def synchronize(self):
+        _check(self._lib.inflx_synchronize(self._h))
+
+
+def open_inflx_dylib(lib_path: str, check_basis: bool = True, device: int = 0) -> InflatoxDevLib:
+    """Counterpart of ``libinflx_rs.open_inflx_dylib(lib_path, check_basis)`` (src/lib.rs:108-115).
+
+    The random-point basis check (lib.rs:142-202) is a load-time guard outside the sweep path and is
+    not performed on the device; ``check_basis`` is accepted for signature compatibility.
+    """
+    return InflatoxDevLib(lib_path, device=device)

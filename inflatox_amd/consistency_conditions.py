@@ -1,0 +1,129 @@
+"""Python front-end of the sweep: ``GeneralisedAL(artifact).complete_analysis(...)``.
+
+Same class names, method names, argument order, defaults and return contracts as the
+reference's front-end (python/inflatox/consistency_conditions.py:31-715); every method hands
+its arrays to ``libinflx_hip.so`` (through :mod:`inflatox_amd._native`) where the reference hands
+them to ``libinflx_rs``.  Extensions that the reference lacks are keyword-only (``device``) or
+separate methods (``complete_analysis_batch``), so reference call sites run unchanged.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+from . import _native
+from ._native import InflatoxDevLib, open_inflx_dylib
+from .compiler import CompilationArtifact
+
+__all__ = ["InflationCondition", "GeneralisedAL"]
+
+
+def _start_stop(x0_start, x0_stop, x1_start, x1_stop) -> np.ndarray:
+    # consistency_conditions.py:292-294: rows = fields, columns = (start, stop)
+    return np.array([[float(x0_start), float(x0_stop)], [float(x1_start), float(x1_stop)]])
+
+
+class InflationCondition:
+    """Base class: owns the opened model artefact (reference consistency_conditions.py:31-50)."""
+
+    def __init__(self, compiled_artifact: CompilationArtifact, validate_basis: bool = True, *, device: int = 0):
+        self.artifact = compiled_artifact
+        self.dylib: InflatoxDevLib = open_inflx_dylib(compiled_artifact.shared_object_path, validate_basis, device=device)
+
+    # -- scalar helpers (reference :52-65,103-117); evaluated on the device through the raw op ----
+    def _raw_at(self, x, args) -> np.ndarray:
+        x = np.asarray(x, dtype=np.float64).reshape(1, 2)
+        return self.dylib.sweep_on_trajectory(_native.OP_RAW, args, x)[0]
+
+    def calc_V(self, x: np.ndarray, args: np.ndarray) -> float:
+        """Scalar potential at field-space point ``x``."""
+        return float(self._raw_at(x, args)[0])
+
+    def calc_H(self, x: np.ndarray, args: np.ndarray) -> np.ndarray:
+        """Projected Hesse matrix at ``x``.  The sweep kernels carry v00, v10, v11 only (Hesse2D never
+        calls v01, hesse_bindings.rs:213-231); the matrix is symmetric, so v01 is filled from v10."""
+        r = self._raw_at(x, args)
+        return np.array([[r[1], r[2]], [r[2], r[3]]])
+
+
+class GeneralisedAL(InflationCondition):
+    """Generalised Anguelova-Lazaroiu consistency condition and the quantities derived from it
+    (reference consistency_conditions.py:199-715)."""
+
+    def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0):
+        super().__init__(compiled_artifact, device=device)
+
+    # ---- the hot path ------------------------------------------------------------------------
+    def complete_analysis(
+        self,
+        args: np.ndarray,
+        x0_start: float,
+        x0_stop: float,
+        x1_start: float,
+        x1_stop: float,
+        N_x0: int = 1_000,
+        N_x1: int = 1_000,
+        progress: bool = True,
+        threads: None | int = None,
+    ) -> tuple[np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray, np.ndarray]:
+        """Six (N_x0, N_x1) arrays: consistency, ε_V, ε_H, η_∥, δ, ω -- element [i, j] belongs to
+        x0 = x0_start + i·(x0_stop-x0_start)/N_x0, x1 likewise (end point excluded).
+        Reference: consistency_conditions.py:226-308; like there, the six arrays are strided views
+        of one (N_x0, N_x1, 6) array."""
+        out = np.zeros((N_x0, N_x1, 6), dtype=float)
+        start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        threads = threads if threads is not None else 0
+        self.dylib.complete_analysis(args, out, start_stop, progress, threads)
+        return (out[:, :, 0], out[:, :, 1], out[:, :, 2], out[:, :, 3], out[:, :, 4], out[:, :, 5])
+
+    def complete_analysis_batch(
+        self,
+        args: np.ndarray,
+        x0_start: float,
+        x0_stop: float,
+        x1_start: float,
+        x1_stop: float,
+        N_x0: int = 1_000,
+        N_x1: int = 1_000,
+        layout: str = "aos",
+    ) -> np.ndarray:
+        """Extension: ``args`` is (P, n_parameters); returns (P, N_x0, N_x1, 6) (``layout='aos'``)
+        or (P, 6, N_x0, N_x1) (``'soa'``) -- the outer parameter axis of the sweep in one call."""
+        lay = {"aos": _native.LAYOUT_AOS, "soa": _native.LAYOUT_SOA}[layout]
+        ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        return self.dylib.sweep_host(_native.OP_COMPLETE, np.atleast_2d(np.asarray(args, dtype=np.float64)), ss, N_x0, N_x1, layout=lay)
+
+    # ---- single-quantity sweeps (reference :310-475) ---------------------------------------------
+    def _single(self, fn, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads):
+        out = np.zeros((N_x0, N_x1), dtype=float)
+        start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        threads = threads if threads is not None else 0
+        fn(args, out, start_stop, progress, threads)
+        return out
+
+    def consistency(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000, progress=True, threads=None) -> np.ndarray:
+        return self._single(self.dylib.consistency_only, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads)
+
+    def epsilon_v(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000, progress=True, threads=None) -> np.ndarray:
+        return self._single(self.dylib.epsilon_v_only, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads)
+
+    def consistency_rapidturn(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000, progress=True, threads=None) -> np.ndarray:
+        return self._single(self.dylib.consistency_rapidturn_only, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads)
+
+    # ---- on-trajectory variants (reference :529-715) ---------------------------------------------
+    def complete_analysis_ot(self, args, x, progress=True, threads=None):
+        threads = threads if threads is not None else 1
+        out = self.dylib.sweep_on_trajectory(_native.OP_COMPLETE, args, x, progress, threads)
+        return np.split(out, 6, 1)
+
+    def consistency_ot(self, args, x, progress=True, threads=None) -> np.ndarray:
+        threads = threads if threads is not None else 1
+        return self.dylib.sweep_on_trajectory(_native.OP_CONSISTENCY, args, x, progress, threads)
+
+    def consistency_rapidturn_ot(self, args, x, progress=True, threads=None) -> np.ndarray:
+        threads = threads if threads is not None else 1
+        return self.dylib.sweep_on_trajectory(_native.OP_RAPIDTURN, args, x, progress, threads)
+
+    def epsilon_v_ot(self, args, x, progress=True, threads=None) -> np.ndarray:
+        threads = threads if threads is not None else 1
+        return self.dylib.sweep_on_trajectory(_native.OP_EPSILON_V, args, x, progress, threads)

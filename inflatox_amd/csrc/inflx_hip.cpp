@@ -1,0 +1,470 @@
+// libinflx_hip.so -- host side of the MI355X grid sweep (C ABI declared in include/inflx_hip.h).
+//
+// Replaces, for the sweep path only, what the reference does in Rust:
+//   src/dylib.rs          open the per-model artefact, check its ABI version, read its globals
+//   src/hesse_bindings.rs bind the five model functions           (here: resolve the kernels)
+//   src/anguelova.rs      validate shapes, convert ranges, drive the loop over grid points
+// The loop itself runs on the GPU (csrc/inflx_sweep_kernels.hip); this file owns the code object,
+// one stream, the parameter buffer and the chunk buffers of a model, and launches kernels with
+// hipModuleLaunchKernel.  No CPU fallback exists: without a usable HIP device every entry point
+// fails with INFLX_ERR_DEVICE.
+#include "inflx_hip.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cerrno>
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "inflx_kernel_abi.h"
+
+namespace {
+
+thread_local std::string g_last_error;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(INFLX_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+
+constexpr uint16_t kAbiMajor = 5, kAbiMinor = 0;  // src/lib.rs:50 V_INFLX_ABI
+const char* const kOpNames[INFLX_OP_COUNT] = {"complete", "consistency", "rapidturn", "epsilon_v", "raw"};
+constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5};
+
+// device chunk used by the host-result path: two buffers of this many bytes at most
+constexpr size_t kChunkBytes = size_t(512) << 20;
+
+}  // namespace
+
+struct inflx_model {
+  int device = 0;
+  hipModule_t module = nullptr;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;
+  hipFunction_t tile[INFLX_OP_COUNT] = {};
+  hipFunction_t rows[INFLX_OP_COUNT] = {};
+  hipFunction_t traj[INFLX_OP_COUNT] = {};
+  InflxKernelInfo info = {};
+  uint16_t version[3] = {};
+  uint32_t dim = 0, n_par = 0;
+  std::string name, path;
+  double* d_params = nullptr;
+  size_t d_params_cap = 0;
+  void* d_chunk[2] = {nullptr, nullptr};
+  size_t d_chunk_cap[2] = {0, 0};
+  hipEvent_t chunk_done[2] = {nullptr, nullptr};
+  hipEvent_t copy_done[2] = {nullptr, nullptr};
+  hipEvent_t t0 = nullptr, t1 = nullptr;
+};
+
+namespace {
+
+template <typename T>
+int read_global(inflx_model* m, const char* sym, T* dst, size_t bytes, bool exact) {
+  hipDeviceptr_t dptr = nullptr;
+  size_t size = 0;
+  if (hipModuleGetGlobal(&dptr, &size, m->module, sym) != hipSuccess)
+    return fail(INFLX_ERR_SYMBOL, "artefact %s lacks symbol %s", m->path.c_str(), sym);
+  if (exact ? size != bytes : size > bytes)
+    return fail(INFLX_ERR_SYMBOL, "symbol %s in %s has %zu bytes, expected %s%zu", sym, m->path.c_str(), size,
+                exact ? "" : "<= ", bytes);
+  HIP_TRY(hipMemcpy(dst, dptr, size, hipMemcpyDeviceToHost));
+  return INFLX_OK;
+}
+
+int ensure_params(inflx_model* m, const double* p, size_t count, hipStream_t s) {
+  if (count > m->d_params_cap) {
+    if (m->d_params) HIP_TRY(hipFree(m->d_params));
+    m->d_params = nullptr;
+    size_t cap = std::max<size_t>(count, 64);
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_params), cap * sizeof(double)));
+    m->d_params_cap = cap;
+  }
+  HIP_TRY(hipMemcpyAsync(m->d_params, p, count * sizeof(double), hipMemcpyHostToDevice, s));
+  return INFLX_OK;
+}
+
+// validate_lib + validiate_p (src/anguelova.rs:55-79) and the Hesse2D guard (hesse_bindings.rs:203)
+int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (op < 0 || op >= INFLX_OP_COUNT) return fail(INFLX_ERR_ARG, "unknown sweep operation %d", op);
+  if (m->dim != 2)
+    return fail(INFLX_ERR_SHAPE, "the Anguelova & Lazaroiu consistency condition requires a 2-field model (model has %u fields)",
+                m->dim);
+  if (n_p != m->n_par)
+    return fail(INFLX_ERR_SHAPE, "model \"%s\" has %u paramters (got %zu)", m->name.c_str(), m->n_par, n_p);
+  if (!p && n_p) return fail(INFLX_ERR_ARG, "parameter array is NULL");
+  if (P == 0) return fail(INFLX_ERR_SHAPE, "parameter array has no rows");
+  return INFLX_OK;
+}
+
+// Enqueue one sweep launch on `s`; `d_params` points at P parameter rows in device memory.
+int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
+                size_t row_begin, size_t row_count, int layout, hipStream_t s) {
+  if (row_count == 0 || N1 == 0) return INFLX_OK;
+  InflxSweepArgs a;
+  memset(&a, 0, sizeof a);
+  a.out = d_out;
+  a.params = d_params;
+  // convert_ranges (src/anguelova.rs:84-94): spacing = (stop - start) / N, offset = start
+  a.x0a = ss[0];
+  a.dx0 = (ss[1] - ss[0]) / (double)N0;
+  a.x1a = ss[2];
+  a.dx1 = (ss[3] - ss[2]) / (double)N1;
+  a.N1 = N1;
+  a.row_begin = row_begin;
+  a.row_count = row_count;
+  a.P = (uint32_t)P;
+  a.layout = (uint32_t)layout;
+  a.col_chunks = 1;
+  void* params[] = {&a};
+  const bool row_uniform = (m->info.out_mask & 2u) == 0;
+  if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
+  if (row_uniform) {
+    const size_t rpb = m->info.rows_per_block;
+    const size_t groups = (row_count + rpb - 1) / rpb;
+    // few rows: split each row into column chunks until the grid can fill 256 CUs x 8 workgroups
+    size_t chunks = 1;
+    const size_t want = 4096;
+    if (groups * P < want) {
+      const size_t units = (kOpWidth[op] == 6 && layout == INFLX_AOS) ? 3 * N1 / 192 : N1 / 64;
+      chunks = std::min<size_t>(std::max<size_t>(units, 1), (want + groups * P - 1) / (groups * P));
+    }
+    if (groups * chunks > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid too large for one launch");
+    a.col_chunks = (uint32_t)chunks;
+    HIP_TRY(hipModuleLaunchKernel(m->rows[op], (unsigned)(groups * chunks), (unsigned)P, 1, m->info.tile_cols, 1, 1, 0, s, params,
+                                  nullptr));
+  } else {
+    const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
+    const size_t gy = (row_count + m->info.tile_rows - 1) / m->info.tile_rows;
+    if (gy > 65535 || gx > 0x7fffffffULL)
+      return fail(INFLX_ERR_SHAPE, "grid too large for one launch (%zu x %zu tiles); sweep fewer rows per call", gx, gy);
+    HIP_TRY(hipModuleLaunchKernel(m->tile[op], (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params,
+                                  nullptr));
+  }
+  return INFLX_OK;
+}
+
+int ensure_chunk(inflx_model* m, int which, size_t bytes) {
+  if (bytes <= m->d_chunk_cap[which]) return INFLX_OK;
+  if (m->d_chunk[which]) HIP_TRY(hipFree(m->d_chunk[which]));
+  m->d_chunk[which] = nullptr;
+  m->d_chunk_cap[which] = 0;
+  HIP_TRY(hipMalloc(&m->d_chunk[which], bytes));
+  m->d_chunk_cap[which] = bytes;
+  return INFLX_OK;
+}
+
+void say(const char* fmt, ...) {
+  // the reference's BADGE_INFO lines (src/lib.rs:53-66, src/anguelova.rs:492,543-547)
+  va_list ap;
+  va_start(ap, fmt);
+  fputs("[Inflatox Info] ", stderr);
+  vfprintf(stderr, fmt, ap);
+  fputc('\n', stderr);
+  fflush(stderr);
+  va_end(ap);
+}
+
+int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+               int progress, const char* what) {
+  if (!out) return fail(INFLX_ERR_ARG, "output array is NULL");
+  if (!ss) return fail(INFLX_ERR_ARG, "start_stop array is NULL");
+  int rc = validate(m, op, p, 1, n_p);
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (progress) say("Calculating %s on HIP device %d (%s).", what, m->device, m->name.c_str());
+  rc = inflx_sweep_host(m, op, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS);
+  if (rc) return rc;
+  if (progress) {
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    say("Calculation finished. Took %.3f s.", sec);
+  }
+  return INFLX_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* inflx_last_error(void) { return g_last_error.c_str(); }
+
+int inflx_device_count(int* count) {
+  if (!count) return fail(INFLX_ERR_ARG, "count is NULL");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(INFLX_ERR_DEVICE, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  return INFLX_OK;
+}
+
+int inflx_open(const char* artefact_path, int device, inflx_model** out) {
+  if (!artefact_path || !out) return fail(INFLX_ERR_ARG, "artefact path / output handle is NULL");
+  *out = nullptr;
+  FILE* fh = fopen(artefact_path, "rb");
+  if (!fh) return fail(INFLX_ERR_IO, "could not open model artefact %s: %s", artefact_path, strerror(errno));
+  fclose(fh);
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+    return fail(INFLX_ERR_DEVICE, "no HIP device available: the sweep has no CPU fallback");
+  if (device < 0 || device >= ndev) return fail(INFLX_ERR_ARG, "device %d out of range (have %d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+
+  inflx_model* m = new inflx_model();
+  m->device = device;
+  m->path = artefact_path;
+  auto bail = [&](int code) {
+    inflx_close(m);
+    return code;
+  };
+  hipError_t e = hipModuleLoad(&m->module, artefact_path);
+  if (e != hipSuccess) {
+    m->module = nullptr;
+    fail(INFLX_ERR_IO, "could not load %s as a gfx950 code object: %s", artefact_path, hipGetErrorString(e));
+    return bail(INFLX_ERR_IO);
+  }
+  int rc;
+  if ((rc = read_global(m, "VERSION", m->version, sizeof m->version, true))) return bail(rc);
+  if (m->version[0] != kAbiMajor || m->version[1] != kAbiMinor) {
+    fail(INFLX_ERR_VERSION, "artefact %s was built for inflatox ABI v%u.%u.%u, this library implements v%u.%u", artefact_path,
+         m->version[0], m->version[1], m->version[2], kAbiMajor, kAbiMinor);
+    return bail(INFLX_ERR_VERSION);
+  }
+  if ((rc = read_global(m, "DIM", &m->dim, sizeof m->dim, true))) return bail(rc);
+  if ((rc = read_global(m, "N_PARAMETERS", &m->n_par, sizeof m->n_par, true))) return bail(rc);
+  char name[512] = {0};
+  if ((rc = read_global(m, "MODEL_NAME", name, sizeof name - 1, false))) return bail(rc);
+  m->name = name;
+  if ((rc = read_global(m, "INFLX_KERNEL_INFO", &m->info, sizeof m->info, true))) return bail(rc);
+  if (m->info.kernel_abi != INFLX_KERNEL_ABI) {
+    fail(INFLX_ERR_VERSION, "artefact %s uses kernel ABI %u, this library expects %u", artefact_path, m->info.kernel_abi,
+         INFLX_KERNEL_ABI);
+    return bail(INFLX_ERR_VERSION);
+  }
+  for (int op = 0; op < INFLX_OP_COUNT; ++op) {
+    const std::string names[3] = {std::string("inflx_sweep_tile_") + kOpNames[op], std::string("inflx_sweep_rows_") + kOpNames[op],
+                                  std::string("inflx_sweep_traj_") + kOpNames[op]};
+    hipFunction_t* slots[3] = {&m->tile[op], &m->rows[op], &m->traj[op]};
+    for (int k = 0; k < 3; ++k) {
+      if (hipModuleGetFunction(slots[k], m->module, names[k].c_str()) != hipSuccess) {
+        fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s", artefact_path, names[k].c_str());
+        return bail(INFLX_ERR_SYMBOL);
+      }
+    }
+  }
+  if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) {
+    fail(INFLX_ERR_DEVICE, "could not create HIP streams");
+    return bail(INFLX_ERR_DEVICE);
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (hipEventCreateWithFlags(&m->chunk_done[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->copy_done[k], hipEventDisableTiming) != hipSuccess) {
+      fail(INFLX_ERR_DEVICE, "could not create HIP events");
+      return bail(INFLX_ERR_DEVICE);
+    }
+  }
+  if (hipEventCreate(&m->t0) != hipSuccess || hipEventCreate(&m->t1) != hipSuccess) {
+    fail(INFLX_ERR_DEVICE, "could not create HIP timing events");
+    return bail(INFLX_ERR_DEVICE);
+  }
+  *out = m;
+  return INFLX_OK;
+}
+
+void inflx_close(inflx_model* m) {
+  if (!m) return;
+  (void)hipSetDevice(m->device);
+  if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
+  for (int k = 0; k < 2; ++k) {
+    if (m->d_chunk[k]) (void)hipFree(m->d_chunk[k]);
+    if (m->chunk_done[k]) (void)hipEventDestroy(m->chunk_done[k]);
+    if (m->copy_done[k]) (void)hipEventDestroy(m->copy_done[k]);
+  }
+  if (m->t0) (void)hipEventDestroy(m->t0);
+  if (m->t1) (void)hipEventDestroy(m->t1);
+  if (m->d_params) (void)hipFree(m->d_params);
+  if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+  if (m->module) (void)hipModuleUnload(m->module);
+  delete m;
+}
+
+uint32_t inflx_n_fields(const inflx_model* m) { return m ? m->dim : 0; }
+uint32_t inflx_n_parameters(const inflx_model* m) { return m ? m->n_par : 0; }
+const char* inflx_model_name(const inflx_model* m) { return m ? m->name.c_str() : ""; }
+int inflx_device_of(const inflx_model* m) { return m ? m->device : -1; }
+
+int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t* nc, uint32_t* out_mask) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (nu) *nu = m->info.n_uniform;
+  if (nr) *nr = m->info.n_row;
+  if (nc) *nc = m->info.n_col;
+  if (out_mask) *out_mask = m->info.out_mask;
+  return INFLX_OK;
+}
+
+int inflx_synchronize(inflx_model* m) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
+                       const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream) {
+  int rc = validate(m, op, p, P, n_p);
+  if (rc) return rc;
+  if (!d_out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
+  if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
+  if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
+  const size_t need = P * row_count * N1 * kOpWidth[op] * sizeof(double);
+  if (d_out_bytes < need) return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, need);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+  if ((rc = ensure_params(m, p, P * n_p, s))) return rc;
+  return launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
+}
+
+int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
+                             const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream,
+                             int repeats, float* ms_per_launch) {
+  if (repeats <= 0 || !ms_per_launch) return fail(INFLX_ERR_ARG, "repeats must be positive and ms_per_launch non-NULL");
+  // first call validates everything and uploads the parameters
+  int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
+  if (rc) return rc;
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+  HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipEventRecord(m->t0, s));
+  for (int k = 0; k < repeats; ++k) {
+    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipEventRecord(m->t1, s));
+  HIP_TRY(hipEventSynchronize(m->t1));
+  float ms = 0.f;
+  HIP_TRY(hipEventElapsedTime(&ms, m->t0, m->t1));
+  *ms_per_launch = ms / (float)repeats;
+  return INFLX_OK;
+}
+
+int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
+                     size_t N1, size_t row_begin, size_t row_count, int layout) {
+  int rc = validate(m, op, p, P, n_p);
+  if (rc) return rc;
+  if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
+  if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
+  if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
+  if (row_count == 0 || N1 == 0) return INFLX_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  if ((rc = ensure_params(m, p, P * n_p, m->stream))) return rc;
+
+  const size_t K = kOpWidth[op];
+  const size_t row_bytes = N1 * K * sizeof(double);
+  // rows per chunk: whole rows of ONE parameter row at a time (keeps every copy contiguous in the
+  // AoS result; the SoA result is copied plane by plane)
+  size_t rows_per_chunk = std::max<size_t>(1, kChunkBytes / row_bytes);
+  rows_per_chunk = std::min(rows_per_chunk, row_count);
+  const size_t chunk_bytes = rows_per_chunk * row_bytes;
+  for (int k = 0; k < 2; ++k)
+    if ((rc = ensure_chunk(m, k, chunk_bytes))) return rc;
+
+  // ping-pong: kernel for chunk c on `stream` into buffer c&1, copy-back on `copy_stream`
+  size_t c = 0;
+  bool used[2] = {false, false};
+  for (size_t pr = 0; pr < P; ++pr) {
+    // a chunk holds rows of a single parameter row: launch with P = 1 at that row's parameters
+    for (size_t r = 0; r < row_count; r += rows_per_chunk, ++c) {
+      const int b = (int)(c & 1);
+      const size_t nrows = std::min(rows_per_chunk, row_count - r);
+      if (used[b]) HIP_TRY(hipStreamWaitEvent(m->stream, m->copy_done[b], 0));
+      rc = launch_grid(m, op, m->d_params + pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + r, nrows, layout,
+                       m->stream);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(m->chunk_done[b], m->stream));
+      HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->chunk_done[b], 0));
+      if (layout == INFLX_AOS || K == 1) {
+        double* dst = out + (pr * row_count + r) * N1 * K;
+        HIP_TRY(hipMemcpyAsync(dst, m->d_chunk[b], nrows * row_bytes, hipMemcpyDeviceToHost, m->copy_stream));
+      } else {
+        for (size_t k = 0; k < K; ++k) {
+          double* dst = out + ((pr * K + k) * row_count + r) * N1;
+          const double* src = static_cast<const double*>(m->d_chunk[b]) + k * nrows * N1;
+          HIP_TRY(hipMemcpyAsync(dst, src, nrows * N1 * sizeof(double), hipMemcpyDeviceToHost, m->copy_stream));
+        }
+      }
+      HIP_TRY(hipEventRecord(m->copy_done[b], m->copy_stream));
+      used[b] = true;
+    }
+  }
+  HIP_TRY(hipStreamSynchronize(m->copy_stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+int inflx_complete_analysis(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+                            int progress, size_t /*threads*/) {
+  return grid_entry(m, INFLX_OP_COMPLETE, p, n_p, out, ss, N0, N1, progress, "full analysis");
+}
+int inflx_consistency_only(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+                           int progress, size_t /*threads*/) {
+  return grid_entry(m, INFLX_OP_CONSISTENCY, p, n_p, out, ss, N0, N1, progress, "consistency condition");
+}
+int inflx_consistency_rapidturn_only(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0,
+                                     size_t N1, int progress, size_t /*threads*/) {
+  return grid_entry(m, INFLX_OP_RAPIDTURN, p, n_p, out, ss, N0, N1, progress, "consistency condition (rapid-turn limit)");
+}
+int inflx_epsilon_v_only(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+                         int progress, size_t /*threads*/) {
+  return grid_entry(m, INFLX_OP_EPSILON_V, p, n_p, out, ss, N0, N1, progress, "potential slow-roll parameter ε_V");
+}
+
+int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_p, const double* x, size_t n, double* out,
+                              int progress, size_t /*threads*/) {
+  int rc = validate(m, op, p, 1, n_p);
+  if (rc) return rc;
+  if (n == 0) return INFLX_OK;
+  if (!x || !out) return fail(INFLX_ERR_ARG, "trajectory / output pointer is NULL");
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t K = kOpWidth[op];
+  const size_t in_bytes = n * 2 * sizeof(double), out_bytes = n * K * sizeof(double);
+  if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
+  if ((rc = ensure_chunk(m, 1, in_bytes))) return rc;
+  if ((rc = ensure_params(m, p, n_p, m->stream))) return rc;
+  if (progress) say("Calculating on trajectory (%zu points) on HIP device %d.", n, m->device);
+  HIP_TRY(hipMemcpyAsync(m->d_chunk[1], x, in_bytes, hipMemcpyHostToDevice, m->stream));
+  InflxTrajectoryArgs a;
+  memset(&a, 0, sizeof a);
+  a.out = static_cast<double*>(m->d_chunk[0]);
+  a.params = m->d_params;
+  a.points = static_cast<const double*>(m->d_chunk[1]);
+  a.n = n;
+  a.P = 1;
+  void* params[] = {&a};
+  const size_t gx = (n + m->info.tile_cols - 1) / m->info.tile_cols;
+  HIP_TRY(hipModuleLaunchKernel(m->traj[op], (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
+  HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+}  // extern "C"

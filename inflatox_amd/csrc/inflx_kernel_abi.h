@@ -1,0 +1,65 @@
+// Contract between the per-model code object (device side) and libinflx_hip.so (host side).
+// Plain C types only; shared by inflx_sweep_kernels.hip and inflx_hip.cpp.
+#pragma once
+#include <stdint.h>
+
+#define INFLX_KERNEL_ABI 3u
+
+// which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
+enum InflxOp {
+  INFLX_OP_COMPLETE = 0,     // ops::complete_analysis          6 f64 per point
+  INFLX_OP_CONSISTENCY = 1,  // ops::consistency_only           1 f64
+  INFLX_OP_RAPIDTURN = 2,    // ops::consistency_rapidturn_only 1 f64
+  INFLX_OP_EPSILON_V = 3,    // ops::epsilon_v_only             1 f64
+  INFLX_OP_RAW = 4,          // V, v00, v10, v11, |dV|^2        5 f64 (diagnostic; pins the model functions)
+  INFLX_OP_COUNT = 5
+};
+
+// output memory layout for multi-value operations
+enum InflxLayout {
+  INFLX_LAYOUT_AOS = 0,  // [P][rows][N1][K]   the reference's (N0,N1,6) array per parameter row
+  INFLX_LAYOUT_SOA = 1   // [P][K][rows][N1]   K contiguous planes per parameter row
+};
+
+// Launch arguments of every grid-sweep kernel (passed by value).
+//
+// A launch evaluates rows [row_begin, row_begin + row_count) of the full N0 x N1 grid for P
+// parameter rows.  Row i, column j maps to the field-space point
+//   x0 = (double)i * dx0 + x0a,   x1 = (double)j * dx1 + x1a            (src/anguelova.rs:531-533)
+// Output element (p, i, j, k), AOS:  out[((p*row_count + (i-row_begin))*N1 + j)*K + k]
+//                               SOA:  out[((p*K + k)*row_count + (i-row_begin))*N1 + j]
+struct InflxSweepArgs {
+  double* out;
+  const double* params;  // [P][N_PARAMETERS], device memory
+  double x0a, dx0, x1a, dx1;
+  uint64_t N1;
+  uint64_t row_begin;
+  uint64_t row_count;
+  uint32_t P;
+  uint32_t layout;      // InflxLayout
+  uint32_t col_chunks;  // row kernels: number of column chunks a row is split into
+  uint32_t reserved;
+};
+
+// Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch
+// (src/anguelova.rs:633-977); out[(p*n + idx)*K + k].
+struct InflxTrajectoryArgs {
+  double* out;
+  const double* params;
+  const double* points;  // [n][2]
+  uint64_t n;
+  uint32_t P;
+  uint32_t reserved;
+};
+
+// Read by the host from the code object's INFLX_KERNEL_INFO global after loading it.
+struct InflxKernelInfo {
+  uint32_t kernel_abi;  // INFLX_KERNEL_ABI
+  uint32_t n_uniform;   // exported U-stage values
+  uint32_t n_row;       // exported R-stage values (doubles of LDS per tile row)
+  uint32_t n_col;       // exported C-stage values (registers per thread)
+  uint32_t out_mask;    // bit0: some model value depends on x[0]; bit1: on x[1]
+  uint32_t tile_rows;   // rows per workgroup tile of the tile kernels
+  uint32_t tile_cols;   // columns per workgroup tile (= threads per workgroup)
+  uint32_t rows_per_block;  // rows per workgroup of the row-broadcast kernels
+};

@@ -1,0 +1,326 @@
+// Grid-sweep kernels for one inflation model, gfx950 (MI355X / CDNA4) only.
+//
+// Compiled once per model by inflatox_amd.Compiler:
+//   hipcc --offload-arch=gfx950 --genco -O3 -DINFLX_MODEL_HEADER="<generated>.h" this_file -o model.hsaco
+// The generated header provides the model as four straight-line device functions
+// (inflx_stage_uniform / _row / _col / _point, see inflatox_amd/compiler.py) that are inlined
+// here -- the counterpart of the reference calling V, v11, v10, v00, grad_norm_squared through
+// five dlsym'd pointers per grid point (src/anguelova.rs:110,119; src/hesse_bindings.rs:213-231).
+//
+// Work decomposition (replaces rayon's par_chunks_exact_mut(6) over points, anguelova.rs:526-539):
+//
+//  * tile kernels (inflx_sweep_tile_*): a 256-thread workgroup owns a tile of TILE_ROWS grid rows
+//    x 256 grid columns for one parameter row.  Lane <-> column j (the fast axis of the output),
+//    so a wavefront covers 64 consecutive points of one grid row = 64*K*8 contiguous bytes.
+//    Column-only sub-expressions are evaluated once per thread and live in registers; row-only
+//    sub-expressions are evaluated once per tile row by one lane each and are staged in LDS,
+//    from where all lanes read them as a broadcast; parameters sit in registers/SGPRs.
+//    For the 6-value AoS result a wavefront transposes its 64x6 block through a private 3 KiB LDS
+//    buffer so that every global store instruction writes 1 KiB of contiguous memory (16 B/lane).
+//
+//  * row kernels (inflx_sweep_rows_*): used when no model value depends on x[1] (e.g. the
+//    hyperbolic benchmark model): the per-point operation is then a function of the row only, is
+//    evaluated once per grid row, and the kernel degenerates into a pure 48 B/point store stream
+//    (three 16-B patterns rotating over the lanes), which is what the HBM roofline prices.
+//
+// Numerics: IEEE-strict FP64 (no fast-math, denormals kept, correctly rounded div/sqrt).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "inflx_device_math.h"
+#include "inflx_kernel_abi.h"
+#include "inflx_ops.h"
+
+#ifndef INFLX_MODEL_HEADER
+#error "INFLX_MODEL_HEADER must name the generated model header"
+#endif
+#include INFLX_MODEL_HEADER
+
+#ifndef INFLX_TILE_ROWS
+#define INFLX_TILE_ROWS 32
+#endif
+#ifndef INFLX_ROWS_PER_BLOCK
+#define INFLX_ROWS_PER_BLOCK 4
+#endif
+#ifndef INFLX_NT_STORES
+#define INFLX_NT_STORES 1
+#endif
+
+static_assert(INFLX_DIM == 2, "the sweep kernels need a two-field model (Hesse2D, hesse_bindings.rs:203)");
+
+constexpr int kThreads = 256;
+constexpr int kWave = 64;
+constexpr int kTileRows = INFLX_TILE_ROWS;
+constexpr int kRowsPerBlock = INFLX_ROWS_PER_BLOCK;
+constexpr int kNU = INFLX_NU > 0 ? INFLX_NU : 1;
+constexpr int kNR = INFLX_NR > 0 ? INFLX_NR : 1;
+constexpr int kNC = INFLX_NC > 0 ? INFLX_NC : 1;
+constexpr int kNP = INFLX_N_PARAMETERS > 0 ? INFLX_N_PARAMETERS : 1;
+
+typedef double inflx_d2 __attribute__((ext_vector_type(2)));
+
+// ---- metadata the host reads back (counterpart of the dylib's VERSION/DIM/... symbols,
+// ---- src/dylib.rs:32-48, emitted by the reference at compiler.py:546-560) ---------------------
+extern "C" {
+__device__ __attribute__((used)) const uint16_t VERSION[3] = {5, 0, 0};
+__device__ __attribute__((used)) const uint32_t DIM = INFLX_DIM;
+__device__ __attribute__((used)) const uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
+__device__ __attribute__((used)) const char MODEL_NAME[] = INFLX_MODEL_NAME;
+__device__ __attribute__((used)) const char USE_GSL = 0;
+__device__ __attribute__((used)) const InflxKernelInfo INFLX_KERNEL_INFO = {
+    INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK};
+}
+
+template <int OP>
+struct OpWidth {
+  static constexpr int K = (OP == INFLX_OP_COMPLETE) ? 6 : (OP == INFLX_OP_RAW ? 5 : 1);
+};
+
+template <int OP>
+__device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o) {
+  if constexpr (OP == INFLX_OP_COMPLETE) {
+    inflx_op_complete_analysis(mv, o);
+  } else if constexpr (OP == INFLX_OP_CONSISTENCY) {
+    o[0] = inflx_op_consistency_only(mv);
+  } else if constexpr (OP == INFLX_OP_RAPIDTURN) {
+    o[0] = inflx_op_consistency_rapidturn_only(mv);
+  } else if constexpr (OP == INFLX_OP_EPSILON_V) {
+    o[0] = inflx_op_epsilon_v_only(mv);
+  } else {
+    o[0] = mv.V;
+    o[1] = mv.v00;
+    o[2] = mv.v10;
+    o[3] = mv.v11;
+    o[4] = mv.g;
+  }
+}
+
+__device__ __forceinline__ void store_d2(double* p, inflx_d2 v) {
+#if INFLX_NT_STORES
+  __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(p));
+#else
+  *reinterpret_cast<inflx_d2*>(p) = v;
+#endif
+}
+
+__device__ __forceinline__ void store_d1(double* p, double v) {
+#if INFLX_NT_STORES
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
+__device__ __forceinline__ void load_params(const double* __restrict__ params, unsigned p, double* A) {
+#pragma unroll
+  for (int k = 0; k < INFLX_N_PARAMETERS; ++k) A[k] = params[(size_t)p * INFLX_N_PARAMETERS + k];
+}
+
+// ================================================================================================
+// tile kernels: general case (some value depends on x[1])
+// ================================================================================================
+template <int OP>
+__device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
+  constexpr int K = OpWidth<OP>::K;
+  __shared__ double Rs[kTileRows][kNR];
+  __shared__ __attribute__((aligned(16))) double tbuf[kThreads / kWave][kWave * 6];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & (kWave - 1);
+  const unsigned wave = tid / kWave;
+  const unsigned p = blockIdx.z;
+
+  double A[kNP];
+  load_params(a.params, p, A);
+  double U[kNU];
+  inflx_stage_uniform(A, U);
+
+  const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
+  const uint64_t j = col0 + tid;
+  const double x1 = inflx_coord(j, a.dx1, a.x1a);
+  double C[kNC];
+  inflx_stage_col(x1, A, U, C);
+
+  const uint64_t row0 = (uint64_t)blockIdx.y * kTileRows;  // relative to row_begin
+  const uint64_t left = a.row_count - row0;
+  const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
+  if ((int)tid < nrows) {
+    const double x0 = inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a);
+    inflx_stage_row(x0, A, U, Rs[tid]);
+  }
+  __syncthreads();
+
+  const bool in_range = j < a.N1;
+  const uint64_t wave_col0 = col0 + (uint64_t)wave * kWave;
+  // 16-byte units of this wavefront's 64-point block that lie inside the row (AoS, K = 6)
+  const uint64_t cols_left = wave_col0 < a.N1 ? a.N1 - wave_col0 : 0;
+  const unsigned wave_units = cols_left >= kWave ? 3u * kWave : 3u * (unsigned)cols_left;
+
+  for (int r = 0; r < nrows; ++r) {
+    const uint64_t row = row0 + r;
+    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
+    InflxModelValues mv;
+    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+    double o[K];
+    apply_op<OP>(mv, o);
+
+    if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
+      if (in_range) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j;
+          store_d1(a.out + off, o[k]);
+        }
+      }
+    } else if constexpr (K == 6) {
+      // wave-private transpose: lane l holds point l's 6 values; after it lane l holds the
+      // l-th, (64+l)-th and (128+l)-th 16-byte unit of the block's 3072 contiguous bytes
+      double* tb = tbuf[wave];
+      inflx_d2* mine = reinterpret_cast<inflx_d2*>(tb + lane * 6);
+      mine[0] = inflx_d2{o[0], o[1]};
+      mine[1] = inflx_d2{o[2], o[3]};
+      mine[2] = inflx_d2{o[4], o[5]};
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + wave_col0) * 6;
+      const inflx_d2* units = reinterpret_cast<const inflx_d2*>(tb);
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned q = s * kWave + lane;
+        const inflx_d2 v = units[q];
+        if (q < wave_units) store_d2(dst + 2 * q, v);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    } else {
+      if (in_range) {
+        double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + j) * K;
+#pragma unroll
+        for (int k = 0; k < K; ++k) store_d1(dst + k, o[k]);
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// row kernels: no model value depends on x[1]  ->  one evaluation per grid row, broadcast along it
+// ================================================================================================
+template <int OP>
+__device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
+  constexpr int K = OpWidth<OP>::K;
+  __shared__ double vals[kRowsPerBlock][8];
+
+  const unsigned tid = threadIdx.x;
+  const unsigned lane = tid & (kWave - 1);
+  const unsigned wave = tid / kWave;
+  const unsigned p = blockIdx.y;
+  const uint64_t group = blockIdx.x / a.col_chunks;
+  const unsigned chunk = blockIdx.x % a.col_chunks;
+  const uint64_t row0 = group * kRowsPerBlock;
+
+  if (tid < kRowsPerBlock && row0 + tid < a.row_count) {
+    double A[kNP];
+    load_params(a.params, p, A);
+    double U[kNU], R[kNR], C[kNC];
+    inflx_stage_uniform(A, U);
+    const double x0 = inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a);
+    inflx_stage_row(x0, A, U, R);
+    // by construction of this kernel nothing below reads x1 or C
+    InflxModelValues mv;
+    inflx_stage_point(x0, a.x1a, A, U, R, C, mv);
+    double o[K];
+    apply_op<OP>(mv, o);
+#pragma unroll
+    for (int k = 0; k < K; ++k) vals[tid][k] = o[k];
+  }
+  __syncthreads();
+
+  // waves stride over the block's rows (kRowsPerBlock may exceed the 4 waves of a workgroup)
+  for (unsigned rr = wave; rr < (unsigned)kRowsPerBlock; rr += kThreads / kWave) {
+    const uint64_t row = row0 + rr;
+    if (row >= a.row_count) break;
+    double v[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) v[k] = vals[rr][k];
+
+    if (K == 6 && a.layout == INFLX_LAYOUT_AOS) {
+      // The row is N1 copies of the same 48 bytes.  In 16-byte units u = 0 .. 3*N1-1 the content
+      // of unit u is pair (u mod 3); lane l issues units l, l+64, l+128, ... and 64 mod 3 == 1,
+      // so it cycles through three register pairs.
+      inflx_d2 pr[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        const unsigned t = (lane + s) % 3;
+        pr[s] = inflx_d2{t == 0 ? v[0] : (t == 1 ? v[2] : v[4]), t == 0 ? v[1] : (t == 1 ? v[3] : v[5])};
+      }
+      const uint64_t units = 3 * a.N1;
+      // column chunking in multiples of 192 units keeps the rotation phase
+      const uint64_t per_chunk = ((units + a.col_chunks - 1) / a.col_chunks + 191) / 192 * 192;
+      const uint64_t u_begin = (uint64_t)chunk * per_chunk;
+      const uint64_t u_end = u_begin + per_chunk < units ? u_begin + per_chunk : units;
+      double* dst = a.out + ((uint64_t)p * a.row_count + row) * a.N1 * 6;
+      for (uint64_t u = u_begin + lane; u < u_end; u += 192) {
+        store_d2(dst + 2 * u, pr[0]);
+        if (u + 64 < u_end) store_d2(dst + 2 * (u + 64), pr[1]);
+        if (u + 128 < u_end) store_d2(dst + 2 * (u + 128), pr[2]);
+      }
+    } else {
+      const uint64_t per_chunk = ((a.N1 + a.col_chunks - 1) / a.col_chunks + kWave - 1) / kWave * kWave;
+      const uint64_t j_begin = (uint64_t)chunk * per_chunk;
+      const uint64_t j_end = j_begin + per_chunk < a.N1 ? j_begin + per_chunk : a.N1;
+      for (uint64_t j = j_begin + lane; j < j_end; j += kWave) {
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+          const uint64_t off = a.layout == INFLX_LAYOUT_SOA ? (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j
+                                                            : (((uint64_t)p * a.row_count + row) * a.N1 + j) * K + k;
+          store_d1(a.out + off, v[k]);
+        }
+      }
+    }
+  }
+}
+
+// ================================================================================================
+// on-trajectory kernels: explicit (n,2) point list (src/anguelova.rs:633-977)
+// ================================================================================================
+template <int OP>
+__device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
+  constexpr int K = OpWidth<OP>::K;
+  const uint64_t idx = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned p = blockIdx.y;
+  if (idx >= a.n) return;
+  double A[kNP];
+  load_params(a.params, p, A);
+  double U[kNU], R[kNR], C[kNC];
+  const double x0 = a.points[2 * idx], x1 = a.points[2 * idx + 1];
+  inflx_stage_uniform(A, U);
+  inflx_stage_row(x0, A, U, R);
+  inflx_stage_col(x1, A, U, C);
+  InflxModelValues mv;
+  inflx_stage_point(x0, x1, A, U, R, C, mv);
+  double o[K];
+  apply_op<OP>(mv, o);
+  double* dst = a.out + ((uint64_t)p * a.n + idx) * K;
+#pragma unroll
+  for (int k = 0; k < K; ++k) dst[k] = o[k];
+}
+
+// ---- entry points (looked up by name with hipModuleGetFunction) --------------------------------
+#define INFLX_DEFINE_KERNELS(NAME, OP)                                                                   \
+  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_tile_##NAME(const InflxSweepArgs a) { \
+    sweep_tile<OP>(a);                                                                                   \
+  }                                                                                                      \
+  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rows_##NAME(const InflxSweepArgs a) { \
+    if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rows<OP>(a);                                          \
+  }                                                                                                      \
+  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_traj_##NAME(const InflxTrajectoryArgs a) { \
+    sweep_trajectory<OP>(a);                                                                             \
+  }
+
+INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)
+INFLX_DEFINE_KERNELS(consistency, INFLX_OP_CONSISTENCY)
+INFLX_DEFINE_KERNELS(rapidturn, INFLX_OP_RAPIDTURN)
+INFLX_DEFINE_KERNELS(epsilon_v, INFLX_OP_EPSILON_V)
+INFLX_DEFINE_KERNELS(raw, INFLX_OP_RAW)

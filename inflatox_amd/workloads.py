@@ -1,0 +1,33 @@
+"""Build-and-cache helpers for the named example models (used by build(), tests and bench.py).
+
+``artifact_for(name)`` runs the symbolic stage and the transpiler for one of
+``example_models.ALL`` and returns ``(spec, CompilationArtifact)``.  The hipcc step is served from
+the content-addressed in-tree cache (``inflatox_amd/_jit_cache``) when ``build()`` has run before;
+the symbolic stage is cheap (0.2-10 s) and always re-run, so the cache key -- the generated header
+text -- is recomputed rather than trusted.
+"""
+
+from __future__ import annotations
+
+import functools
+
+from . import example_models
+from .compiler import CompilationArtifact, Compiler
+from .symbolic import InflationModel, InflationModelBuilder
+
+
+@functools.lru_cache(maxsize=None)
+def model_for(name: str) -> InflationModel:
+    spec = example_models.get(name)
+    builder = InflationModelBuilder.new(
+        spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
+    )
+    return builder.build(spec.guesses)
+
+
+def artifact_for(name: str, **compiler_overrides) -> tuple[example_models.ModelSpec, CompilationArtifact]:
+    spec = example_models.get(name)
+    kwargs = dict(spec.compiler_kwargs)
+    kwargs.update(compiler_overrides)
+    art = Compiler(model_for(name), silent=True, **kwargs).compile()
+    return spec, art

@@ -38,6 +38,28 @@ REFERENCE_FLAGS = [
 ]
 
 
+# The reference's preamble (compiler.py:72-88) defines the M_* constants itself when <math.h> does
+# not (it does not under the strict -std=c17 the reference compiles with, on glibc and musl), and
+# it defines them TRUNCATED to 12 significant digits.  That is the arithmetic the reference
+# actually performs, so the oracle restates it.
+FALLBACK_CONSTANTS = """#ifndef M_PI
+#define M_E 2.71828182846
+#define M_LOG2E 1.44269504089
+#define M_LOG10E 0.4342944819
+#define M_LN2 0.69314718056
+#define M_LN10 2.30258509299
+#define M_PI 3.14159265359
+#define M_PI_2 1.57079632679
+#define M_PI_4 0.78539816339
+#define M_1_PI 0.31830988618
+#define M_2_PI 0.63661977236
+#define M_2_SQRTPI 1.1283791671
+#define M_SQRT2 1.41421356237
+#define M_SQRT_1_2 0.70710678118
+#endif
+"""
+
+
 class _OraclePrinter(C99CodePrinter):
     """C99 printer with the reference's symbol-mapping rules."""
 
@@ -141,7 +163,7 @@ def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool
             )
         body += _scalar_fn("double eomh(const double x[], const double xdot[], const double args[])", model.eom_h, pr, cse, max_cses)
         body += _scalar_fn("double eomhdot(const double x[], const double xdot[], const double args[])", model.eom_hdot, pr, cse, max_cses)
-    head = "#include <math.h>\n#include <stdint.h>\n"
+    head = "#include <math.h>\n#include <stdint.h>\n" + FALLBACK_CONSTANTS
     head += f"const uint16_t VERSION[3] = {{{ABI_VERSION[0]},{ABI_VERSION[1]},{ABI_VERSION[2]}}};\n"
     head += f"const uint32_t DIM = {dim};\n"
     head += f"const uint32_t N_PARAMETERS = {len(pr.params)};\n"

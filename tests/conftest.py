@@ -1,0 +1,61 @@
+"""Shared fixtures.  `-m gpu` tests need an MI355X; everything else runs on the CPU container."""
+
+import functools
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
+MODELS = ("hyperbolic", "doc", "angular", "egno", "d5")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@functools.lru_cache(maxsize=None)
+def golden(name):
+    return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
+
+
+@functools.lru_cache(maxsize=None)
+def oracle_model(name):
+    """The CPU oracle for an example model: this repo's symbolic stage -> oracle C emitter -> gcc."""
+    import oracle
+    from inflatox_amd import example_models, workloads
+
+    spec = example_models.get(name)
+    src, symdict = oracle.emit_c_source(workloads.model_for(name), **spec.compiler_kwargs)
+    return oracle.OracleModel(oracle.compile_c_model(src)), symdict
+
+
+def compare(got, want, rtol, what=""):
+    """NaN pattern exact, +-Inf exact, finite values within rtol relative."""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern differs"
+    inf = np.isinf(want)
+    assert np.array_equal(np.isinf(got), inf), f"{what}: Inf pattern differs"
+    assert np.array_equal(got[inf], want[inf]), f"{what}: Inf signs differ"
+    fin = np.isfinite(want)
+    if fin.any():
+        err = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), np.finfo(float).tiny)
+        assert err.max() <= rtol, f"{what}: max relative error {err.max():.3e} > {rtol:g}"
+        return float(err.max())
+    return 0.0
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    from inflatox_amd import _native
+
+    _native.load_library()
+    assert _native.device_count() > 0, "no HIP device visible"
+    return _native

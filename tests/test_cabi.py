@@ -1,0 +1,51 @@
+"""The C-ABI library loads and exports every symbol include/inflx_hip.h declares (no compute)."""
+
+import ctypes
+import os
+import re
+
+from conftest import ROOT
+
+
+def _declared_functions():
+    text = open(os.path.join(ROOT, "include", "inflx_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(inflx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_the_expected_surface():
+    names = _declared_functions()
+    for must in ("inflx_open", "inflx_close", "inflx_complete_analysis", "inflx_sweep_device", "inflx_sweep_host", "inflx_last_error"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol():
+    from inflatox_amd import _native
+
+    _native.build_library()
+    lib = ctypes.CDLL(_native.LIB_PATH)
+    for name in _declared_functions():
+        assert hasattr(lib, name), f"libinflx_hip.so lacks {name}"
+
+
+def test_binding_covers_the_header():
+    from inflatox_amd import _native
+
+    assert sorted(_native.SIGNATURES) == _declared_functions()
+    _native.load_library()
+
+
+def test_open_fails_loudly_without_artefact_or_device():
+    """No CPU fallback: a missing artefact is an IOError; with no GPU, opening a real one is a SystemError."""
+    import pytest
+
+    from inflatox_amd import _native
+
+    with pytest.raises(IOError):
+        _native.InflatoxDevLib("/nonexistent/model.hsaco")
+    if _native.device_count() == 0:
+        from inflatox_amd import workloads
+
+        _, art = workloads.artifact_for("hyperbolic")
+        with pytest.raises(SystemError):
+            _native.InflatoxDevLib(art.shared_object_path)
