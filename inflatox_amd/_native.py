@@ -84,6 +84,27 @@ def build_library(force: bool = False) -> str:
     return LIB_PATH
 
 
+def _preload_hip_runtime():
+    """Make sure the process ends up with ONE HIP runtime.
+
+    PyTorch wheels bundle their own ``libamdhip64.so`` (SONAME libamdhip64.so.7) and request it by
+    the unversioned name; ``libinflx_hip.so`` requests ``libamdhip64.so.7``.  If this library were
+    loaded first it would pull in /opt/rocm's copy, a later ``import torch`` would then load the
+    bundled copy as a *second* runtime, and torch would find no devices.  Loading torch's copy
+    first (by path, without importing torch) lets both requests resolve to the same object.
+    """
+    import importlib.util
+
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is not None and spec.origin:
+        cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+        if os.path.exists(cand):
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+
+
 def load_library():
     """Load ``libinflx_hip.so`` and declare every entry point; raises if it is missing."""
     global _lib
@@ -93,6 +114,7 @@ def load_library():
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(the sweep has no CPU fallback)"
             )
+        _preload_hip_runtime()
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol

@@ -9,10 +9,10 @@ with the hand-written sweep kernels (``csrc/inflx_sweep_kernels.hip``) into a pe
 gfx950 code object.  What that buys (none of it available across the reference's dylib
 boundary):
 
-  * cross-function common-subexpression elimination over V, v00, v10, v11 and |dV|^2;
-  * *axis staging*: every sub-expression is classified by which grid axis it depends on --
-    nothing but parameters (U), x[0] only (R, "row"), x[1] only (C, "column"), or both (P,
-    "point") -- and is evaluated once per kernel / per row / per column / per point
+  * sub-expressions shared between V, v00, v10, v11 and |dV|^2 are evaluated once;
+  * *axis staging* (see staging.py): every sub-expression is classified by which grid axis it
+    depends on -- nothing but parameters (U), x[0] only (R, "row"), x[1] only (C, "column"), or
+    both (P, "point") -- and is evaluated once per kernel / per row / per column / per point
     respectively.  The kernels keep R values in LDS and C values in registers;
   * integer and half-integer powers become multiplication chains (the reference leaves
     ``pow(x, 4)`` to libm; OCML's generic f64 pow costs hundreds of VALU instructions).
@@ -30,11 +30,11 @@ import shutil
 import subprocess
 import sys
 import tempfile
-from collections import defaultdict
 
 import sympy
 from sympy.printing.c import C99CodePrinter
 
+from .staging import HIPInflatoxPrinter, emit_stage_header  # noqa: F401  (HIPInflatoxPrinter re-exported)
 from .symbolic import InflationModel
 from .version import __abi_version__, __version__
 
@@ -113,326 +113,6 @@ class CInflatoxPrinter(C99CodePrinter):
         return None
 
 
-class HIPInflatoxPrinter(C99CodePrinter):
-    """Prints staged expressions as HIP device code.
-
-    Symbols are resolved through an explicit name table (fields -> ``x0``/``x1``, parameters ->
-    ``args[k]``, stage temporaries -> their C identifiers); an unknown symbol is an error here,
-    because parameter numbering is fixed beforehand by the reference-order registration pass.
-    """
-
-    MAX_INT_POW = 64
-
-    def __init__(self, names: dict, constants: dict):
-        super().__init__()
-        self.names = names
-        # constants print as INFLX_<macro>, defined in the generated header
-        self.math_macros = {k: "INFLX_" + v for k, v in self.math_macros.items()}
-        self.constants = constants
-
-    def _print_Symbol(self, expr):
-        try:
-            return self.names[expr]
-        except KeyError:
-            raise KeyError(f"symbol {expr!r} was not registered before printing") from None
-
-    def _print_Integer(self, expr):
-        v = int(expr)
-        return str(v) if abs(v) < 2**31 else f"{v}.0"
-
-    def _print_Pow(self, expr):
-        base, exp = expr.base, expr.exp
-        if exp.is_Integer:
-            n = int(exp)
-            if 2 <= abs(n) <= self.MAX_INT_POW:
-                body = f"inflx_ipow<{abs(n)}>({self._print(base)})"
-                return body if n > 0 else f"(1.0/{body})"
-        elif exp.is_Rational and exp.q == 2:
-            n = int(exp.p)
-            if 3 <= abs(n) <= 2 * self.MAX_INT_POW:
-                body = f"inflx_hpow<{abs(n)}>({self._print(base)})"
-                return body if n > 0 else f"(1.0/{body})"
-        return super()._print_Pow(expr)
-
-    # functions without a C99 spelling
-    def _print_coth(self, e):
-        return f"inflx_coth({self._print(e.args[0])})"
-
-    def _print_sech(self, e):
-        return f"inflx_sech({self._print(e.args[0])})"
-
-    def _print_csch(self, e):
-        return f"inflx_csch({self._print(e.args[0])})"
-
-    def _print_cot(self, e):
-        return f"inflx_cot({self._print(e.args[0])})"
-
-    def _print_sec(self, e):
-        return f"inflx_sec({self._print(e.args[0])})"
-
-    def _print_csc(self, e):
-        return f"inflx_csc({self._print(e.args[0])})"
-
-
-# ---------------------------------------------------------------------------------------------
-# axis staging
-# ---------------------------------------------------------------------------------------------
-
-# dependence masks: bit 0 = depends on x[0] (row axis), bit 1 = depends on x[1] (column axis)
-_U, _R, _C, _P = 0, 1, 2, 3
-_STAGE_PREFIX = {_U: "u", _R: "r", _C: "c", _P: "p"}
-
-
-class StagedProgram:
-    """The five model quantities as four straight-line programs (U, R, C, P stages).
-
-    ``defs[m]``     ordered list of (symbol, expression) evaluated in stage m;
-    ``outputs``     five expressions/symbols for V, v00, v10, v11, |dV|^2 (each an atom or stage symbol);
-    ``out_mask``    OR of the dependence masks of the five outputs;
-    ``exports[m]``  symbols of stage m that a later stage reads (these cross LDS/registers).
-    """
-
-    def __init__(self, exprs, x0, x1):
-        self.x0, self.x1 = x0, x1
-        self.defs = {_U: [], _R: [], _C: [], _P: []}
-        self._mask_of_symbol = {x0: _R, x1: _C}
-        self._stage_of_symbol = {}
-        self._memo = {_U: {}, _R: {}, _C: {}, _P: {}}
-        self._mask_cache = {}
-        self._counter = defaultdict(int)
-        self._rename = {}  # sympy.cse temporaries -> stage symbols
-
-        sys.setrecursionlimit(max(sys.getrecursionlimit(), 20000))
-        replacements, reduced = sympy.cse(list(exprs), symbols=sympy.numbered_symbols("_inflx_cse"), order="canonical")
-        for sym, definition in replacements:
-            definition = definition.xreplace(self._rename)
-            m = self._mask(definition)
-            new_sym = self._new_symbol(m)
-            self._rename[sym] = new_sym
-            self.defs[m].append((new_sym, self._lower(definition, m)))
-        self.outputs = []
-        self.out_masks = []
-        for e in reduced:
-            e = e.xreplace(self._rename)
-            m = self._mask(e)
-            self.out_masks.append(m)
-            self.outputs.append(self._as_atom(e, m))
-        self.out_mask = 0
-        for m in self.out_masks:
-            self.out_mask |= m
-        self._compute_exports()
-
-    # -- helpers ------------------------------------------------------------------------------
-    def _new_symbol(self, m):
-        k = self._counter[m]
-        self._counter[m] += 1
-        s = sympy.Symbol(f"{_STAGE_PREFIX[m]}_{k}", real=True)
-        self._stage_of_symbol[s] = m
-        self._mask_of_symbol[s] = m
-        return s
-
-    def _mask(self, e):
-        """Which grid axes does ``e`` depend on?"""
-        if e.is_Symbol:
-            return self._mask_of_symbol.get(e, _U)
-        if e.is_Atom:
-            return _U
-        got = self._mask_cache.get(e)
-        if got is None:
-            got = 0
-            for a in e.args:
-                got |= self._mask(a)
-                if got == _P:
-                    break
-            self._mask_cache[e] = got
-        return got
-
-    def _as_atom(self, e, m):
-        """Return a symbol/number standing for ``e`` (class m), defining a stage variable if needed."""
-        if e.is_Atom:
-            return e
-        if not e.free_symbols:
-            return e  # pure number: the device compiler folds it
-        hit = self._memo[m].get(e)
-        if hit is not None:
-            return hit
-        sym = self._new_symbol(m)
-        self._memo[m][e] = sym
-        self.defs[m].append((sym, self._lower(e, m)))
-        return sym
-
-    def _lower(self, e, ctx):
-        """Rewrite ``e`` (evaluated in stage ctx): maximal sub-trees that depend on fewer axes
-        than ctx are moved to their own stage and replaced by that stage's symbol."""
-        if e.is_Atom:
-            return e
-        m = self._mask(e)
-        if m != ctx:
-            return self._as_atom(e, m)
-        if e.is_Add or e.is_Mul:
-            groups = defaultdict(list)
-            for a in e.args:
-                groups[self._mask(a)].append(a)
-            if len(groups) == 1:
-                return e.func(*[self._lower(a, ctx) for a in e.args])
-            parts = []
-            for gm, items in groups.items():
-                if gm == ctx:
-                    parts.extend(self._lower(a, ctx) for a in items)
-                else:
-                    sub = e.func(*items) if len(items) > 1 else items[0]
-                    parts.append(self._as_atom(sub, gm))
-            return e.func(*parts)
-        return e.func(*[self._lower(a, ctx) for a in e.args])
-
-    def _compute_exports(self):
-        used_by = defaultdict(set)
-        for m, lst in self.defs.items():
-            for _, d in lst:
-                for s in d.free_symbols:
-                    sm = self._stage_of_symbol.get(s)
-                    if sm is not None and sm != m:
-                        used_by[s].add(m)
-        for o in self.outputs:
-            if o.is_Symbol and o in self._stage_of_symbol:
-                used_by[o].add("out")
-        self.exports = {m: [s for s, _ in self.defs[m] if s in used_by] for m in (_U, _R, _C)}
-        self.imports = defaultdict(list)  # stage (or "out") -> exported symbols it reads
-        for m in (_U, _R, _C):
-            for s in self.exports[m]:
-                for user in used_by[s]:
-                    self.imports[user].append(s)
-
-    def op_count(self):
-        return {m: sum(int(sympy.count_ops(d)) for _, d in lst) for m, lst in self.defs.items()}
-
-
-def _emit_stage_header(model: InflationModel, param_slots: dict, constants: dict, model_name: str, staged: bool = True) -> tuple[str, dict]:
-    """Return (header text, info dict) for the model."""
-    x0, x1 = model.coordinates
-    exprs = [
-        sympy.sympify(model.potential),
-        sympy.sympify(model.hesse_cmp[0][0]),
-        sympy.sympify(model.hesse_cmp[1][0]),
-        sympy.sympify(model.hesse_cmp[1][1]),
-        sympy.sympify(model.gradient_square),
-    ]
-    tangents = set(model.coordinate_tangents)
-    for e in exprs:
-        if e.free_symbols & tangents:
-            raise Exception("potential / Hesse expressions may not depend on field velocities")
-    if staged:
-        prog = StagedProgram(exprs, x0, x1)
-    else:
-        prog = _unstaged_program(exprs, x0, x1)
-
-    plain = C99CodePrinter()._print_Symbol
-    names = {x0: "x0", x1: "x1"}
-    for s in set().union(*[e.free_symbols for e in exprs]) - {x0, x1}:
-        names[s] = param_slots[plain(s)]
-    for m, lst in prog.defs.items():
-        for s, _ in lst:
-            names[s] = s.name
-    pr = HIPInflatoxPrinter(names, constants)
-
-    idx = {m: {s: k for k, s in enumerate(prog.exports[m])} for m in (_U, _R, _C)}
-    arr = {_U: "U", _R: "R", _C: "C"}
-
-    def imports_for(user):
-        lines = []
-        for s in prog.imports.get(user, []):
-            m = prog._stage_of_symbol[s]
-            lines.append(f"  const double {s.name} = {arr[m]}[{idx[m][s]}];")
-        return lines
-
-    def body(m):
-        lines = imports_for(m)
-        for s, d in prog.defs[m]:
-            lines.append(f"  const double {s.name} = {pr.doprint(d)};")
-        if m in idx:
-            for s, k in idx[m].items():
-                lines.append(f"  {arr[m]}[{k}] = {s.name};")
-        return "\n".join(lines)
-
-    n_par = len(param_slots)
-    nu, nr, nc = (len(prog.exports[m]) for m in (_U, _R, _C))
-    ops = prog.op_count()
-    out = []
-    out.append("// Generated by inflatox_amd.Compiler -- do not edit.")
-    out.append(f"// model: {model_name}; inflatox_amd v{__version__}; ABI v{__abi_version__}")
-    out.append("#pragma once")
-    for k, v in constants.items():
-        out.append(f"#define INFLX_{k} {v}")
-    out.append(f"#define INFLX_N_PARAMETERS {n_par}")
-    out.append(f"#define INFLX_DIM {model.dim}")
-    out.append(f'#define INFLX_MODEL_NAME "{model_name}"')
-    out.append(f"#define INFLX_NU {nu}")
-    out.append(f"#define INFLX_NR {nr}")
-    out.append(f"#define INFLX_NC {nc}")
-    out.append(f"#define INFLX_OUT_MASK {prog.out_mask}")
-    out.append(f"// sympy op counts per stage: U={ops[_U]} R={ops[_R]} C={ops[_C]} P={ops[_P]}")
-    out.append("")
-    sig_tail = "[[maybe_unused]] const double* __restrict__ args"
-    out.append("// parameter-only sub-expressions (wave-uniform)")
-    out.append(f"__device__ __forceinline__ void inflx_stage_uniform({sig_tail}, [[maybe_unused]] double* __restrict__ U) {{")
-    out.append(body(_U))
-    out.append("}\n")
-    out.append("// sub-expressions of x[0] (and parameters): once per grid row")
-    out.append(
-        f"__device__ __forceinline__ void inflx_stage_row([[maybe_unused]] const double x0, {sig_tail}, "
-        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] double* __restrict__ R) {"
-    )
-    out.append(body(_R))
-    out.append("}\n")
-    out.append("// sub-expressions of x[1] (and parameters): once per grid column")
-    out.append(
-        f"__device__ __forceinline__ void inflx_stage_col([[maybe_unused]] const double x1, {sig_tail}, "
-        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] double* __restrict__ C) {"
-    )
-    out.append(body(_C))
-    out.append("}\n")
-    out.append("// everything that depends on both axes, and the five model values")
-    out.append(
-        f"__device__ __forceinline__ void inflx_stage_point([[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {sig_tail}, "
-        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] const double* __restrict__ R, "
-        "[[maybe_unused]] const double* __restrict__ C, InflxModelValues& mv) {"
-    )
-    lines = imports_for(_P)
-    have = {s for s in prog.imports.get(_P, [])}
-    for s in prog.imports.get("out", []):
-        if s not in have:
-            m = prog._stage_of_symbol[s]
-            lines.append(f"  const double {s.name} = {arr[m]}[{idx[m][s]}];")
-            have.add(s)
-    for s, d in prog.defs[_P]:
-        lines.append(f"  const double {s.name} = {pr.doprint(d)};")
-    for field, o in zip(("V", "v00", "v10", "v11", "g"), prog.outputs):
-        lines.append(f"  mv.{field} = {pr.doprint(o)};")
-    out.append("\n".join(lines))
-    out.append("}\n")
-    info = dict(nu=nu, nr=nr, nc=nc, out_mask=prog.out_mask, out_masks=list(prog.out_masks), ops={str(k): v for k, v in ops.items()})
-    return "\n".join(out), info
-
-
-class _UnstagedProgram:
-    pass
-
-
-def _unstaged_program(exprs, x0, x1):
-    """Debug/parity switch: no CSE, no staging -- the five expressions are printed as they are
-    (like the reference's five separate C functions) and evaluated per grid point."""
-    prog = _UnstagedProgram()
-    prog.defs = {_U: [], _R: [], _C: [], _P: []}
-    prog.outputs = list(exprs)
-    prog.out_masks = [_P] * 5
-    prog.out_mask = _P
-    prog.exports = {_U: [], _R: [], _C: []}
-    prog.imports = defaultdict(list)
-    prog._stage_of_symbol = {}
-    prog.op_count = lambda: {_U: 0, _R: 0, _C: 0, _P: sum(int(sympy.count_ops(e)) for e in exprs)}
-    return prog
-
-
 # ---------------------------------------------------------------------------------------------
 # artefact + compiler front-end
 # ---------------------------------------------------------------------------------------------
@@ -492,9 +172,18 @@ def hipcc_path() -> str:
 class Compiler:
     """Turns an :class:`InflationModel` into a gfx950 code object holding the sweep kernels.
 
-    Same constructor as the reference (compiler.py:315-325).  ``cse``/``max_cses`` only affect
-    parameter numbering (they change the reference's print order, hence must be mirrored);
-    device code is always jointly CSE'd and axis-staged unless ``staged=False``.
+    Same constructor as the reference (compiler.py:315-325) plus keyword extensions:
+
+    * ``cse``/``max_cses`` are honoured exactly like the reference honours them: with ``cse=True``
+      every function is passed through the same ``sympy.cse`` call first (this changes both the
+      parameter numbering and the arithmetic the reference performs, so it is mirrored);
+    * ``staged`` (default True): share identical sub-expressions and evaluate each in the stage of
+      the grid axes it depends on (staging.py); ``False`` evaluates everything per grid point;
+    * ``regroup`` (default False): additionally re-associate mixed products/sums so that row-only
+      and column-only operands are combined before the per-point ones (faster, but rounding differs
+      from the reference where a model cancels catastrophically);
+    * ``exact_constants`` (default False): full-precision pi, e, ... instead of the reference's
+      12-digit fallback constants.
     """
 
     c_prefix = "inflx_auto_"
@@ -503,6 +192,7 @@ class Compiler:
     default_hipcc_flags = [
         "--offload-arch=gfx950",
         "--genco",
+        "--no-gpu-bundle-output",  # plain gfx950 ELF, loadable by hipModuleLoad and readable by llvm-readelf
         "-O3",
         "-std=c++17",
         "-fno-fast-math",
@@ -525,6 +215,7 @@ class Compiler:
         compiler_flags: list[str] | None = None,
         staged: bool = True,
         exact_constants: bool = False,
+        regroup: bool = False,
     ):
         if link_gsl:
             raise NotImplementedError("GSL special functions have no device implementation; link_gsl is not supported by the HIP back-end")
@@ -537,6 +228,7 @@ class Compiler:
         self.cse = cse
         self.max_cses = max_cses
         self.staged = staged
+        self.regroup = regroup
         self.constants = dict(_EXACT_CONSTANTS if exact_constants else _REFERENCE_CONSTANTS)
         self.hipcc_opts = list(compiler_flags) if compiler_flags is not None else list(self.default_hipcc_flags)
         self.symbol_dict = None
@@ -610,7 +302,23 @@ class Compiler:
         self.symbol_dict, params = self._number_parameters()
         if not self.silent and self.cse:
             print("Converting sympy to HIP using common subexpression elimination...")
-        text, info = _emit_stage_header(self.symbolic_out, params, self.constants, self.symbolic_out.model_name, staged=self.staged)
+        cse = None
+        if self.cse:
+            # exactly the reference's per-function call (compiler.py:403-404)
+            def cse(expr):
+                return sympy.cse(expr, symbols=self._cse_symbols(), order="none", list=False)
+
+        text, info = emit_stage_header(
+            self.symbolic_out,
+            params,
+            self.constants,
+            self.symbolic_out.model_name,
+            __version__,
+            __abi_version__,
+            staged=self.staged,
+            cse=cse,
+            regroup=self.regroup,
+        )
         self.stage_info = info
         return text
 

@@ -6,7 +6,7 @@
 // given identical (V, v00, v10, v11, |dV|^2) inputs the results differ from the reference's
 // only through atan/tan (libm vs OCML, <= 1-2 ulp).
 #pragma once
-#include <hip/hip_runtime.h>
+#include "inflx_device_math.h"
 
 struct InflxModelValues {
   double V;    // potential                       (C symbol `V`)
@@ -16,14 +16,14 @@ struct InflxModelValues {
   double g;    // |grad V|^2                       (C symbol `grad_norm_squared`)
 };
 
-__device__ __forceinline__ double inflx_sq(double x) {
+INFLX_FN double inflx_sq(double x) {
 #pragma clang fp contract(off)
   return x * x;  // f64::powi(2)
 }
 
 // ops::complete_analysis, src/anguelova.rs:103-135.
 // out[0] consistency, [1] epsilon_V, [2] epsilon_H, [3] eta_parallel, [4] delta, [5] omega
-__device__ __forceinline__ void inflx_op_complete_analysis(const InflxModelValues& m, double out[6]) {
+INFLX_FN void inflx_op_complete_analysis(const InflxModelValues& m, double out[6]) {
 #pragma clang fp contract(off)
   const double v = m.V, v11 = m.v11, v10 = m.v10, v00 = m.v00;
   double consistency;
@@ -48,13 +48,13 @@ __device__ __forceinline__ void inflx_op_complete_analysis(const InflxModelValue
 }
 
 // ops::epsilon_v_only, src/anguelova.rs:138-140 (note the 1/2 that complete_analysis lacks)
-__device__ __forceinline__ double inflx_op_epsilon_v_only(const InflxModelValues& m) {
+INFLX_FN double inflx_op_epsilon_v_only(const InflxModelValues& m) {
 #pragma clang fp contract(off)
   return 0.5 * m.g / inflx_sq(m.V);
 }
 
 // ops::consistency_rapidturn_only, src/anguelova.rs:143-154
-__device__ __forceinline__ double inflx_op_consistency_rapidturn_only(const InflxModelValues& m) {
+INFLX_FN double inflx_op_consistency_rapidturn_only(const InflxModelValues& m) {
 #pragma clang fp contract(off)
   const double lhs = m.v11 / m.V;
   const double rhs = 3. * inflx_sq(m.v10 / m.v00);
@@ -62,7 +62,7 @@ __device__ __forceinline__ double inflx_op_consistency_rapidturn_only(const Infl
 }
 
 // ops::consistency_only, src/anguelova.rs:157-163
-__device__ __forceinline__ double inflx_op_consistency_only(const InflxModelValues& m) {
+INFLX_FN double inflx_op_consistency_only(const InflxModelValues& m) {
 #pragma clang fp contract(off)
   const double lhs = m.v11 / m.V - 3.;
   const double rhs = 3. * inflx_sq(m.v00 / m.v10) + (m.v00 / m.V) * inflx_sq(m.v10 / m.v00);
@@ -71,7 +71,7 @@ __device__ __forceinline__ double inflx_op_consistency_only(const InflxModelValu
 
 // index -> field-space coordinate, src/anguelova.rs:514-516,531-533: (idx as f64) * spacing + offset,
 // multiply then add (two roundings).
-__device__ __forceinline__ double inflx_coord(unsigned long long idx, double spacing, double offset) {
+INFLX_FN double inflx_coord(unsigned long long idx, double spacing, double offset) {
 #pragma clang fp contract(off)
   return (double)idx * spacing + offset;
 }

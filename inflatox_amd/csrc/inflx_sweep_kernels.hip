@@ -61,15 +61,16 @@ typedef double inflx_d2 __attribute__((ext_vector_type(2)));
 
 // ---- metadata the host reads back (counterpart of the dylib's VERSION/DIM/... symbols,
 // ---- src/dylib.rs:32-48, emitted by the reference at compiler.py:546-560) ---------------------
-extern "C" {
-__device__ __attribute__((used)) const uint16_t VERSION[3] = {5, 0, 0};
-__device__ __attribute__((used)) const uint32_t DIM = INFLX_DIM;
-__device__ __attribute__((used)) const uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
-__device__ __attribute__((used)) const char MODEL_NAME[] = INFLX_MODEL_NAME;
-__device__ __attribute__((used)) const char USE_GSL = 0;
-__device__ __attribute__((used)) const InflxKernelInfo INFLX_KERNEL_INFO = {
+// (non-const on purpose: a const namespace-scope object would get internal linkage and vanish from
+// the code object's dynamic symbol table, where hipModuleGetGlobal looks it up)
+#define INFLX_EXPORT extern "C" __device__ __attribute__((used, visibility("default")))
+INFLX_EXPORT uint16_t VERSION[3] = {5, 0, 0};
+INFLX_EXPORT uint32_t DIM = INFLX_DIM;
+INFLX_EXPORT uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
+INFLX_EXPORT char MODEL_NAME[] = INFLX_MODEL_NAME;
+INFLX_EXPORT char USE_GSL = 0;
+INFLX_EXPORT InflxKernelInfo INFLX_KERNEL_INFO = {
     INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK};
-}
 
 template <int OP>
 struct OpWidth {

@@ -1,0 +1,497 @@
+"""Axis staging: turn the five model expressions into four straight-line device functions.
+
+The sweep evaluates V, v00, v10, v11 and |dV|^2 on a grid x[0] = row axis, x[1] = column axis.
+Every sub-expression is classified by the axes it depends on
+
+    U  parameters only      evaluated once per thread at kernel start (wave-uniform)
+    R  x[0] (+ parameters)  evaluated once per grid row,    kept in LDS
+    C  x[1] (+ parameters)  evaluated once per grid column, kept in registers
+    P  both                 evaluated per grid point
+
+and emitted into the stage it belongs to (``inflx_stage_uniform/_row/_col/_point``).
+
+Hard requirement: *the arithmetic must stay the reference's arithmetic*.  The reference prints each
+expression with sympy's C printer and evaluates it as written; at singular points of a model
+(0/0 forms where a basis vector degenerates, e.g. theta = k*pi in the D5 model) the result -- NaN or
+a cancellation artefact -- depends on the exact form of the expression, and any algebraic rewrite
+(``sympy.cse`` rebuilds expressions with auto-evaluation, which cancels factors) changes it.  So
+this module never builds new sympy expressions from rewritten pieces.  It only
+
+  * shares *structurally identical* sub-expressions (the same node is computed once: exact);
+  * moves *whole* sub-expressions to the stage of the axes they depend on (exact);
+  * inside an n-ary product or sum, multiplies/adds the operands of one class first, in their
+    printed order (a re-association: rounding-level differences only, no cancellation of factors,
+    NaN/Inf propagate the same way);
+  * replaces ``pow(x, n)`` for small integer / half-integer n by a multiplication chain.
+
+Everything is done while printing: :class:`HIPInflatoxPrinter` asks the :class:`Stager` for the
+C expression of every child node, and the stager answers with either the child's own printed form
+or the name of a stage variable that holds it.
+"""
+
+from __future__ import annotations
+
+import sys
+from collections import Counter, defaultdict
+
+import sympy
+from sympy.core.mul import _keep_coeff
+from sympy.printing.c import C99CodePrinter
+from sympy.printing.precedence import PRECEDENCE, precedence
+
+# dependence masks: bit 0 = depends on x[0] (row axis), bit 1 = depends on x[1] (column axis)
+U, R, C, P = 0, 1, 2, 3
+STAGE_PREFIX = {U: "u", R: "r", C: "c", P: "p"}
+ARRAY = {U: "U", R: "R", C: "C"}
+OUTPUT_FIELDS = ("V", "v00", "v10", "v11", "g")
+
+
+def split_product(expr):
+    """The reference printer's view of a product (sympy CodePrinter._print_Mul): a sign, the
+    numerator factors and the denominator factors (as positive powers), in printed order."""
+    c, e = expr.as_coeff_Mul()
+    sign = ""
+    if c < 0:
+        expr = _keep_coeff(-c, e)
+        sign = "-"
+    num, den, paren = [], [], []
+    args = expr.as_ordered_factors() if expr.is_Mul else [expr]
+    for item in args:
+        if item.is_commutative and item.is_Pow and item.exp.is_Rational and item.exp.is_negative:
+            if item.exp != -1:
+                den.append(sympy.Pow(item.base, -item.exp, evaluate=False))
+            else:
+                if len(item.args[0].args) != 1 and isinstance(item.base, sympy.Mul):
+                    paren.append(item)
+                den.append(sympy.Pow(item.base, -item.exp))
+        else:
+            num.append(item)
+    return sign, (num or [sympy.S.One]), den, paren
+
+
+def printed_children(e):
+    """Nodes the printer will ask for when it prints ``e`` (used for reference counting)."""
+    if e.is_Mul:
+        _, num, den, _ = split_product(e)
+        return num + den
+    return list(e.args)
+
+
+class HIPInflatoxPrinter(C99CodePrinter):
+    """C99 printer for device code whose child printing is routed through a :class:`Stager`.
+
+    Symbols resolve through an explicit table (fields -> ``x0``/``x1``, parameters -> ``args[k]``);
+    an unknown symbol is an error, because parameter numbering was fixed beforehand by the
+    reference-order registration pass (compiler.Compiler._number_parameters).
+    """
+
+    MAX_INT_POW = 64
+
+    def __init__(self, names: dict, stager=None):
+        super().__init__()
+        self.names = names
+        self.stager = stager
+        # constants print as INFLX_<macro>; the generated header defines them
+        self.math_macros = {k: "INFLX_" + v for k, v in self.math_macros.items()}
+
+    # -- routing ---------------------------------------------------------------------------------
+    def _print(self, expr, **kwargs):
+        if self.stager is not None and isinstance(expr, sympy.Basic):
+            return self.stager.value(expr)
+        return super()._print(expr, **kwargs)
+
+    def print_node(self, expr):
+        """Print ``expr``'s own operator (children go through :meth:`_print`, i.e. the stager)."""
+        return super()._print(expr)
+
+    # -- atoms -----------------------------------------------------------------------------------
+    def _print_Symbol(self, expr):
+        try:
+            return self.names[expr]
+        except KeyError:
+            raise KeyError(f"symbol {expr!r} was not registered before printing") from None
+
+    def _print_Integer(self, expr):
+        v = int(expr)
+        return str(v) if abs(v) < 2**31 else f"{v}.0"
+
+    # -- operators -------------------------------------------------------------------------------
+    def _print_Pow(self, expr):
+        base, exp = expr.base, expr.exp
+        if exp.is_Integer:
+            n = int(exp)
+            if 2 <= abs(n) <= self.MAX_INT_POW:
+                body = f"inflx_ipow<{abs(n)}>({self._print(base)})"
+                return body if n > 0 else f"(1.0/{body})"
+        elif exp.is_Rational and exp.q == 2:
+            n = int(exp.p)
+            if 3 <= abs(n) <= 2 * self.MAX_INT_POW:
+                body = f"inflx_hpow<{abs(n)}>({self._print(base)})"
+                return body if n > 0 else f"(1.0/{body})"
+        return super()._print_Pow(expr)
+
+    def _operand(self, item, level):
+        """``parenthesize`` for an operand that may have been replaced by a stage variable."""
+        text = self._print(item)
+        if self.stager is not None and self.stager.is_named(item):
+            return text
+        return f"({text})" if precedence(item) <= level else text  # CodePrinter.parenthesize, strict=False
+
+    def _print_Mul(self, expr):
+        prec = precedence(expr)
+        sign, num, den, paren = split_product(expr)
+        if self.stager is not None:
+            num = self.stager.group(num, "*")
+            den = self.stager.group(den, "*")
+        if len(num) == 1 and sign == "-":
+            num_s = [self._operand(num[0], 0.5 * (PRECEDENCE["Pow"] + PRECEDENCE["Mul"]))]
+        else:
+            num_s = [self._operand(x, prec) for x in num]
+        den_s = [self._operand(x, prec) for x in den]
+        for item in paren:
+            if item.base in den:
+                k = den.index(item.base)
+                if not den_s[k].startswith("("):
+                    den_s[k] = f"({den_s[k]})"
+        if not den:
+            return sign + "*".join(num_s)
+        if len(den) == 1:
+            return sign + "*".join(num_s) + "/" + den_s[0]
+        return sign + "*".join(num_s) + "/(" + "*".join(den_s) + ")"
+
+    def _print_Add(self, expr, order=None):
+        terms = self._as_ordered_terms(expr, order=order)
+        if self.stager is not None:
+            terms = self.stager.group(terms, "+")
+        prec = precedence(expr)
+        parts = []
+        for term in terms:
+            t = self._print(term)
+            named = self.stager is not None and self.stager.is_named(term)
+            if t.startswith("-") and not (term.is_Add and not named):
+                sign, t = "-", t[1:]
+            else:
+                sign = "+"
+            if not named and (precedence(term) < prec or term.is_Add):
+                t = f"({t})"
+            parts.extend([sign, t])
+        first = parts.pop(0)
+        return ("" if first == "+" else first) + " ".join(parts)
+
+    # functions without a C99 spelling
+    def _print_coth(self, e):
+        return f"inflx_coth({self._print(e.args[0])})"
+
+    def _print_sech(self, e):
+        return f"inflx_sech({self._print(e.args[0])})"
+
+    def _print_csch(self, e):
+        return f"inflx_csch({self._print(e.args[0])})"
+
+    def _print_cot(self, e):
+        return f"inflx_cot({self._print(e.args[0])})"
+
+    def _print_sec(self, e):
+        return f"inflx_sec({self._print(e.args[0])})"
+
+    def _print_csc(self, e):
+        return f"inflx_csc({self._print(e.args[0])})"
+
+
+class _Group(sympy.AtomicExpr):
+    """Placeholder standing for 'the operands of one class inside an n-ary product/sum'."""
+
+    is_commutative = True
+    is_number = False
+
+    def __new__(cls, op, items):
+        obj = sympy.AtomicExpr.__new__(cls)
+        obj.op = op
+        obj.items = tuple(items)
+        return obj
+
+    def _hashable_content(self):
+        return (self.op, self.items)
+
+    @property
+    def free_symbols(self):
+        return set().union(*[i.free_symbols for i in self.items])
+
+
+class Stager:
+    """Decides, node by node, where a sub-expression is evaluated, and collects the stage code.
+
+    ``staged=False`` turns both sharing and hoisting off: the five expressions are printed as the
+    reference would print them (modulo the pow chains) and evaluated per grid point -- the parity
+    switch that mirrors the reference's five separate C functions.
+    """
+
+    def __init__(self, functions, x0, x1, names, staged=True, regroup=False):
+        """``functions``: one ``(replacements, expression)`` pair per model value, where
+        ``replacements`` is the (possibly empty) list of ``(symbol, definition)`` pairs the
+        reference's per-function ``sympy.cse`` produced; those symbols are local to their function."""
+        sys.setrecursionlimit(max(sys.getrecursionlimit(), 50000))
+        self.regroup = regroup
+        self.staged = staged
+        self.x0, self.x1 = x0, x1
+        self.printer = HIPInflatoxPrinter(names, self)
+        self.lines = {U: [], R: [], C: [], P: []}
+        self.stage_of = {}  # name -> stage
+        self.named = {}  # node -> name
+        self.local = {}  # function-local cse symbol -> (name, mask)
+        self.used_by = defaultdict(set)  # name -> stages (or "out") that read it
+        self._mask = {}
+        self._count = defaultdict(int)
+        self._ctx = P
+        self.refs = Counter()
+        # identical nodes may be shared across the five functions only if no function-local
+        # symbols exist (a node mentioning `cse3` means something else in every function)
+        share_across = all(not repl for repl, _ in functions)
+        if share_across:
+            self._count_refs([e for _, e in functions])
+        self.outputs, self.out_masks = [], []
+        for repl, expr in functions:
+            if not share_across:
+                self.named, self._mask, self.refs, self.local = {}, {}, Counter(), {}
+                self._count_refs([d for _, d in repl] + [expr])
+            for sym, definition in repl:
+                m = self.mask(definition) if staged else P
+                self._ctx = m
+                self.local[sym] = (self._variable(definition, m, reference=False), m)
+            self._ctx = P
+            self.out_masks.append(self.mask(expr) if staged else P)
+            text = self.value(expr)
+            if text in self.stage_of:
+                self.used_by[text].add("out")
+            self.outputs.append(text)
+        self.out_mask = 0
+        for m in self.out_masks:
+            self.out_mask |= m
+        self.exports = {m: [n for n, s in self.stage_of.items() if s == m and (self.used_by[n] - {m})] for m in (U, R, C)}
+
+    def _count_refs(self, roots):
+        if not self.staged:
+            return
+        seen = set()
+        stack = list(roots)
+        while stack:
+            e = stack.pop()
+            if e.is_Atom:
+                continue
+            self.refs[e] += 1
+            if e in seen:
+                continue
+            seen.add(e)
+            stack.extend(printed_children(e))
+
+    # -- classification --------------------------------------------------------------------------
+    def mask(self, e):
+        if e == self.x0:
+            return R
+        if e == self.x1:
+            return C
+        if isinstance(e, _Group):
+            m = 0
+            for i in e.items:
+                m |= self.mask(i)
+            return m
+        if e.is_Atom:
+            return self.local[e][1] if e in self.local else U
+        got = self._mask.get(e)
+        if got is None:
+            got = 0
+            for a in e.args:
+                got |= self.mask(a)
+                if got == P:
+                    break
+            self._mask[e] = got
+        return got
+
+    def is_named(self, e):
+        return e in self.named
+
+    # -- the two questions the printer asks ----------------------------------------------------------
+    def value(self, e):
+        """C text for node ``e`` as an operand in the stage currently being printed."""
+        if isinstance(e, _Group):
+            return self._variable(e, self.mask(e))
+        if e.is_Atom:
+            return self._reference(self.local[e][0]) if e in self.local else self.printer.print_node(e)
+        if not self.staged:
+            return self.printer.print_node(e)
+        if e in self.named:
+            return self._reference(self.named[e])
+        if not e.free_symbols:
+            return self.printer.print_node(e)  # pure number: the device compiler folds it
+        if e.is_Mul and len(e.args) == 2 and e.args[0] is sympy.S.NegativeOne and e.args[1].is_Atom:
+            return self.printer.print_node(e)  # -symbol: cheaper to negate in place than to stage
+        m = self.mask(e)
+        if m != self._ctx or self.refs[e] >= 2:
+            return self._variable(e, m)
+        return self.printer.print_node(e)
+
+    def group(self, items, op):
+        """Within an n-ary product/sum printed in stage ctx: merge the operands of each lower class
+        (>= 2 of them) into one placeholder, keeping the printed order otherwise."""
+        if not self.staged or len(items) < 2 or not self.regroup:
+            return items
+        ctx = self._ctx
+        by = defaultdict(list)
+        for it in items:
+            m = self.mask(it)
+            if m != ctx and it.free_symbols:
+                by[m].append(it)
+        merged, done = [], set()
+        for it in items:
+            m = self.mask(it)
+            if m != ctx and it.free_symbols and len(by[m]) >= 2:
+                if m not in done:
+                    done.add(m)
+                    merged.append(_Group(op, by[m]))
+            else:
+                merged.append(it)
+        return merged
+
+    # -- stage variables ---------------------------------------------------------------------------
+    def _reference(self, name):
+        self.used_by[name].add(self._ctx)
+        return name
+
+    def _variable(self, e, m, reference=True):
+        name = self.named.get(e)
+        if name is None:
+            saved = self._ctx
+            self._ctx = m
+            if isinstance(e, _Group):
+                if e.op == "*":
+                    text = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items)
+                else:
+                    text = self._sum_text(e.items)
+            else:
+                text = self.printer.print_node(e)
+            self._ctx = saved
+            k = self._count[m]
+            self._count[m] += 1
+            name = f"{STAGE_PREFIX[m]}_{k}"
+            self.named[e] = name
+            self.stage_of[name] = m
+            self.lines[m].append(f"  const double {name} = {text};")
+        return self._reference(name) if reference else name
+
+    def _sum_text(self, terms):
+        parts = []
+        for term in terms:
+            t = self.printer._print(term)
+            named = self.is_named(term)
+            if t.startswith("-") and not (term.is_Add and not named):
+                sign, t = "-", t[1:]
+            else:
+                sign = "+"
+            if not named and (precedence(term) < PRECEDENCE["Add"] or term.is_Add):
+                t = f"({t})"
+            parts.extend([sign, t])
+        first = parts.pop(0)
+        return ("" if first == "+" else first) + " ".join(parts)
+
+    def statement_counts(self):
+        return {m: len(v) for m, v in self.lines.items()}
+
+
+def emit_stage_header(
+    model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, regroup: bool = False
+):
+    """Return (header text, info dict) for the model.
+
+    ``cse``: ``None``, or a callable ``expr -> (replacements, reduced)`` reproducing the reference's
+    per-function ``sympy.cse`` call (compiler.py:403-410); when given, the reference evaluates the
+    cse'd form, so that form -- not the plain expression -- is what gets staged."""
+    x0, x1 = model.coordinates
+    exprs = [
+        sympy.sympify(model.potential),
+        sympy.sympify(model.hesse_cmp[0][0]),
+        sympy.sympify(model.hesse_cmp[1][0]),
+        sympy.sympify(model.hesse_cmp[1][1]),
+        sympy.sympify(model.gradient_square),
+    ]
+    tangents = set(model.coordinate_tangents)
+    for e in exprs:
+        if e.free_symbols & tangents:
+            raise Exception("potential / Hesse expressions may not depend on field velocities")
+
+    plain = C99CodePrinter()._print_Symbol
+    names = {x0: "x0", x1: "x1"}
+    for sym in set().union(*[e.free_symbols for e in exprs]) - {x0, x1}:
+        names[sym] = param_slots[plain(sym)]
+    functions = [cse(e) if cse is not None else ([], e) for e in exprs]
+    st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup)
+
+    idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}
+
+    def imports_for(*users):
+        lines, have = [], set()
+        for m in (U, R, C):
+            for n in st.exports[m]:
+                if n not in have and any(u in st.used_by[n] for u in users) and st.stage_of[n] not in users:
+                    lines.append(f"  const double {n} = {ARRAY[m]}[{idx[m][n]}];")
+                    have.add(n)
+        return lines
+
+    def body(m):
+        lines = imports_for(m) + st.lines[m]
+        for n, k in idx[m].items():
+            lines.append(f"  {ARRAY[m]}[{k}] = {n};")
+        return "\n".join(lines)
+
+    n_par = len(param_slots)
+    nu, nr, nc = (len(st.exports[m]) for m in (U, R, C))
+    counts = st.statement_counts()
+    out = [
+        "// Generated by inflatox_amd.Compiler -- do not edit.",
+        f"// model: {model_name}; inflatox_amd v{version}; ABI v{abi_version}",
+        "#pragma once",
+    ]
+    for k, v in constants.items():
+        out.append(f"#define INFLX_{k} {v}")
+    out += [
+        f"#define INFLX_N_PARAMETERS {n_par}",
+        f"#define INFLX_DIM {model.dim}",
+        f'#define INFLX_MODEL_NAME "{model_name}"',
+        f"#define INFLX_NU {nu}",
+        f"#define INFLX_NR {nr}",
+        f"#define INFLX_NC {nc}",
+        f"#define INFLX_OUT_MASK {st.out_mask}",
+        f"// statements per stage: U={counts[U]} R={counts[R]} C={counts[C]} P={counts[P]}",
+        "",
+    ]
+    tail = "[[maybe_unused]] const double* __restrict__ args"
+    out.append("// parameter-only sub-expressions (wave-uniform)")
+    out.append(f"INFLX_FN void inflx_stage_uniform({tail}, [[maybe_unused]] double* __restrict__ U) {{")
+    out.append(body(U))
+    out.append("}\n")
+    out.append("// sub-expressions of x[0] (and parameters): once per grid row")
+    out.append(
+        f"INFLX_FN void inflx_stage_row([[maybe_unused]] const double x0, {tail}, "
+        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] double* __restrict__ R) {"
+    )
+    out.append(body(R))
+    out.append("}\n")
+    out.append("// sub-expressions of x[1] (and parameters): once per grid column")
+    out.append(
+        f"INFLX_FN void inflx_stage_col([[maybe_unused]] const double x1, {tail}, "
+        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] double* __restrict__ C) {"
+    )
+    out.append(body(C))
+    out.append("}\n")
+    out.append("// everything that depends on both axes, and the five model values")
+    out.append(
+        f"INFLX_FN void inflx_stage_point([[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {tail}, "
+        "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] const double* __restrict__ R, "
+        "[[maybe_unused]] const double* __restrict__ C, InflxModelValues& mv) {"
+    )
+    lines = imports_for(P, "out") + st.lines[P]
+    for field, text in zip(OUTPUT_FIELDS, st.outputs):
+        lines.append(f"  mv.{field} = {text};")
+    out.append("\n".join(lines))
+    out.append("}\n")
+    info = dict(nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()})
+    return "\n".join(out), info

@@ -85,6 +85,42 @@ def load_reference():
     return symbolic, compiler
 
 
+def mp_truth(model, compiler_param_dict, args, ext, n0, n1, digits=50):
+    """50-digit evaluation (mpmath) of V, v00, v10, v11, |dV|^2 at the float64 grid coordinates, with
+    the float64 parameter values and the reference's 12-digit M_* constants (compiler.py:72-88), rounded
+    to float64: the exact value of what the reference's C *means*, against which its rounding error --
+    and therefore the agreement that can be demanded of any other implementation -- is measured."""
+    import mpmath
+    import sympy
+    from sympy.printing.c import C99CodePrinter
+
+    mpmath.mp.dps = digits
+    consts = {
+        sympy.pi: sympy.Float("3.14159265359", digits),
+        sympy.E: sympy.Float("2.71828182846", digits),
+    }
+    exprs = [model.potential, model.hesse_cmp[0][0], model.hesse_cmp[1][0], model.hesse_cmp[1][1], model.gradient_square]
+    exprs = [sympy.sympify(e).xreplace(consts) for e in exprs]
+    x0, x1 = model.coordinates
+    plain = C99CodePrinter()._print_Symbol
+    params = sorted((s for s in set().union(*[e.free_symbols for e in exprs]) - {x0, x1}), key=lambda s: int(compiler_param_dict[plain(s)][5:-1]))
+    fn = sympy.lambdify([x0, x1, *params], exprs, modules="mpmath", cse=True)
+    pvals = [mpmath.mpf(float(args[int(compiler_param_dict[plain(s)][5:-1])])) for s in params]
+    dx0 = (ext[1] - ext[0]) / n0
+    dx1 = (ext[3] - ext[2]) / n1
+    out = np.full((n0, n1, 5), np.nan)
+    for i in range(n0):
+        for j in range(n1):
+            a = mpmath.mpf(float(i * dx0 + ext[0]))  # the float64 coordinate the sweep uses
+            b = mpmath.mpf(float(j * dx1 + ext[2]))
+            try:
+                vals = fn(a, b, *pvals)
+                out[i, j] = [float(mpmath.re(v)) if mpmath.im(v) == 0 else np.nan for v in vals]
+            except (ZeroDivisionError, ValueError, OverflowError):
+                pass  # singular point: no finite truth
+    return out
+
+
 # grids: (tag, N0, N1, extent or None for the spec's default)
 GRIDS = {
     "hyperbolic": [("g16", 16, 16, None), ("g64", 64, 48, None), ("ragged", 7, 13, (-0.9, 1.3, 0.1, 2.0))],
@@ -142,6 +178,8 @@ def main(models):
             out[f"{tag}_consistency"] = om.grid_sweep(OP.CONSISTENCY, spec.args, ext, n0, n1)
             out[f"{tag}_rapidturn"] = om.grid_sweep(OP.RAPIDTURN, spec.args, ext, n0, n1)
             out[f"{tag}_epsilon_v"] = om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1)
+            if tag in ("g16", "g64"):
+                out[f"{tag}_raw_mp"] = mp_truth(model, comp.symbol_dict, spec.args, ext, n0, n1)
         if name == "doc":
             # the reference's only known-answer test on this path: tests/test_doc.py:50-51
             x = np.array([2.0, -2.0])

@@ -49,3 +49,25 @@ def test_open_fails_loudly_without_artefact_or_device():
         _, art = workloads.artifact_for("hyperbolic")
         with pytest.raises(SystemError):
             _native.InflatoxDevLib(art.shared_object_path)
+
+
+def test_code_object_exports_the_model_abi():
+    """The per-model artefact carries the reference's data symbols (src/dylib.rs:32-48) and the kernels."""
+    import shutil
+    import subprocess
+
+    from inflatox_amd import workloads
+
+    readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    if not os.path.exists(readelf):
+        import pytest
+
+        pytest.skip("llvm-readelf not available")
+    _, art = workloads.artifact_for("hyperbolic")
+    table = subprocess.run([readelf, "-s", "--dyn-syms", art.shared_object_path], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in table.splitlines() if " GLOBAL " in ln}
+    for sym in ("VERSION", "DIM", "N_PARAMETERS", "MODEL_NAME", "USE_GSL", "INFLX_KERNEL_INFO"):
+        assert sym in exported, sym
+    for op in ("complete", "consistency", "rapidturn", "epsilon_v", "raw"):
+        for kind in ("tile", "rows", "traj"):
+            assert f"inflx_sweep_{kind}_{op}" in exported
