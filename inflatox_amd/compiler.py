@@ -196,6 +196,10 @@ class Compiler:
         "-O3",
         "-std=c++17",
         "-fno-fast-math",
+        # contraction only within a source statement, like the clang (zig cc) the reference compiles
+        # with; hipcc's default `fast` also fuses across statements, which measurably moves results
+        # away from the reference where a model cancels catastrophically (scripts/contract_experiment.py)
+        "-ffp-contract=on",
         "-fno-gpu-rdc",
         "-Wall",
         "-Werror",

@@ -16,5 +16,5 @@ half of the reference cannot be built in the authoring container (no rustc/cargo
 DESIGN.md "Oracle".
 """
 
-from .cpu_oracle import OracleModel, build_sweep_library, OP  # noqa: F401
+from .cpu_oracle import OP, OracleModel, build_sweep_library, grid_points, raw_long_double  # noqa: F401
 from .model_c import emit_c_source, compile_c_model  # noqa: F401

@@ -55,6 +55,7 @@ def _load():
         lib.oracle_potential.argtypes = [C.c_void_p, dp, dp]
         lib.oracle_potential.restype = C.c_double
         lib.oracle_hesse.argtypes = [C.c_void_p, dp, dp, dp]
+        lib.oracle_raw_long_double.argtypes = [C.c_char_p, dp, C.c_size_t, dp, C.c_size_t, dp]
         _lib = lib
     return _lib
 
@@ -143,3 +144,27 @@ class OracleModel:
 
     def complete_analysis(self, p, extent, N0: int, N1: int, threads: int = 1) -> np.ndarray:
         return self.grid_sweep(OP.COMPLETE, p, extent, N0, N1, threads=threads)
+
+
+def raw_long_double(so_path_ld: str, p, pts) -> np.ndarray:
+    """V, v00, v10, v11, |dV|^2 at the (n,2) points, evaluated in x87 extended precision by a model
+    object built from ``emit_c_source(..., long_double=True)``; rounded to float64, shape (n,5)."""
+    lib = _load()
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((pts.shape[0], 5))
+    rc = lib.oracle_raw_long_double(so_path_ld.encode(), _dptr(p), p.size, _dptr(pts), pts.shape[0], _dptr(out))
+    if rc:
+        raise OracleError(f"[{rc}] {lib.oracle_last_error().decode()}")
+    return out
+
+
+def grid_points(extent, N0: int, N1: int) -> np.ndarray:
+    """The (N0*N1, 2) field-space points of a grid sweep, computed like src/anguelova.rs:531-533
+    (index * spacing + offset, multiply then add, in float64)."""
+    x0a, x0b, x1a, x1b = (float(v) for v in extent)
+    dx0 = (x0b - x0a) / N0
+    dx1 = (x1b - x1a) / N1
+    x0 = np.arange(N0, dtype=np.float64) * dx0 + x0a
+    x1 = np.arange(N1, dtype=np.float64) * dx1 + x1a
+    return np.stack(np.meshgrid(x0, x1, indexing="ij"), axis=-1).reshape(-1, 2)

@@ -143,8 +143,14 @@ def _inner_prod_fn(metric, dim, pr, cse, max_cses):
     return "\n".join(lines) + "\n"
 
 
-def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool = True):
-    """Return ``(c_source, symbol_dictionary)`` for an InflationModel-like object."""
+def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool = True, long_double: bool = False):
+    """Return ``(c_source, symbol_dictionary)`` for an InflationModel-like object.
+
+    ``long_double=True`` emits the same functions in x87 extended precision (64-bit mantissa,
+    ``<tgmath.h>`` dispatching pow/log/... to their ``l`` variants) with ``_ld``-suffixed names.
+    That flavour is not part of the reference; it measures how far the reference's double
+    evaluation is from the exact value of its own expressions, i.e. the agreement that can be
+    demanded of any other correctly-rounding-level implementation at a given point."""
     pr = _OraclePrinter(model.coordinates, model.coordinate_tangents)
     dim = model.dim
     body = _scalar_fn("double V(const double x[], const double args[])", model.potential, pr, cse, max_cses)
@@ -171,7 +177,10 @@ def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool
     head += "const char USE_GSL = 0;\n\n"
     symdict = {k: v for k, v in pr.slots.items() if v.startswith("x[")}
     symdict.update(pr.params)
-    return head + body, symdict
+    src = head + body
+    if long_double:
+        src = src.replace("double", "long double").replace("#include <math.h>", "#include <tgmath.h>")
+    return src, symdict
 
 
 def compile_c_model(c_source: str, out_dir: str | None = None, cc: str = "gcc", flags=None) -> str:

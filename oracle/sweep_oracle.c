@@ -313,3 +313,29 @@ int oracle_hesse(oracle_model *m, const double *x, const double *p, double h[4])
   h[3] = m->v11(x, p);
   return ORACLE_OK;
 }
+
+/* ---- extended-precision evaluation of the model values (not part of the reference) ---------------
+ * Opens a model object emitted with long_double=True (oracle/model_c.py) and evaluates
+ * V, v00, v10, v11, grad_norm_squared at n explicit points in x87 extended precision, rounding the
+ * results to double.  Used by the tests to measure the reference's own rounding error. */
+typedef long double (*exfn2l)(const long double *, const long double *);
+
+int oracle_raw_long_double(const char *so_path, const double *p, size_t n_p, const double *pts, size_t n, double *out) {
+  void *h = dlopen(so_path, RTLD_NOW | RTLD_LOCAL);
+  if (!h) FAIL(ORACLE_EIO, "could not open %s: %s", so_path, dlerror());
+  const char *names[5] = {"V", "v00", "v10", "v11", "grad_norm_squared"};
+  exfn2l fn[5];
+  for (int k = 0; k < 5; ++k) {
+    fn[k] = (exfn2l)dlsym(h, names[k]);
+    if (!fn[k]) { dlclose(h); FAIL(ORACLE_ESYMBOL, "missing symbol %s in %s", names[k], so_path); }
+  }
+  long double *pl = (long double *)malloc(sizeof(long double) * (n_p ? n_p : 1));
+  for (size_t k = 0; k < n_p; ++k) pl[k] = p[k];
+  for (size_t i = 0; i < n; ++i) {
+    const long double x[2] = {pts[2 * i], pts[2 * i + 1]};
+    for (int k = 0; k < 5; ++k) out[5 * i + k] = (double)fn[k](x, pl);
+  }
+  free(pl);
+  dlclose(h);
+  return ORACLE_OK;
+}

@@ -96,8 +96,9 @@ def mp_truth(model, compiler_param_dict, args, ext, n0, n1, digits=50):
 
     mpmath.mp.dps = digits
     consts = {
-        sympy.pi: sympy.Float("3.14159265359", digits),
-        sympy.E: sympy.Float("2.71828182846", digits),
+        # the float64 nearest to the reference's decimal literals, exactly as the C compiler reads them
+        sympy.pi: sympy.Float(float("3.14159265359"), digits),
+        sympy.E: sympy.Float(float("2.71828182846"), digits),
     }
     exprs = [model.potential, model.hesse_cmp[0][0], model.hesse_cmp[1][0], model.hesse_cmp[1][1], model.gradient_square]
     exprs = [sympy.sympify(e).xreplace(consts) for e in exprs]
