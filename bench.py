@@ -32,6 +32,32 @@ HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICR
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
 
 
+def host_threads() -> int:
+    """CPU threads this process may actually use: the cgroup CPU quota if one is set (a GPU box hands
+    each GPU a share of the host), else the scheduler affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def recorded_traffic(kernel: str, model: str, n: int):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None when
+    no measurement of this exact workload is on record."""
+    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("workload", "").startswith(f"{model} {n}x{n} ") and kernel in rec:
+        return rec[kernel]["traffic_bytes"]
+    return None
+
+
 def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     """Oracle (C restatement of the reference's rayon sweep: five indirect calls per point into the
     gcc -O3 model object + ops::complete_analysis) on all host cores, bounded sample."""
@@ -43,7 +69,7 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     spec = example_models.get(model_name)
     src, _ = oracle.emit_c_source(workloads.model_for(model_name), **spec.compiler_kwargs)
     om = oracle.OracleModel(oracle.compile_c_model(src))
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     n = 1024
     t0 = time.perf_counter()
     om.grid_sweep(oracle.OP.COMPLETE, args, extent, n, n, threads=cores)  # warm-up + calibration
@@ -61,7 +87,8 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
         "unit": "grid-points/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"{model_name} {n}x{n} sub-grid of the same extent, best of 3, {cores} threads, gcc -O3 model object + C restatement of the Rust sweep",
+        "sample": f"{model_name} {n}x{n} grid over the same extent (per-point cost does not depend on grid size), best of 3 passes, "
+        f"{cores} threads ({os.cpu_count()} logical CPUs on the host), gcc -O3 -march=native model object + C restatement of the Rust sweep",
     }
 
 
@@ -92,16 +119,19 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     from inflatox_amd import _native, workloads
+    from inflatox_amd.distributed import plan_shard
 
     spec, art = workloads.artifact_for(opt.model)
     lib = _native.InflatoxDevLib(art.shared_object_path, device=local_rank)
 
     N0 = N1 = opt.n
-    # outer parameter axis: one row per rank; rank r gets the r-th value of the last parameter
-    # scaled over [1, 2) (for the hyperbolic model that is L, as in BASELINE configs[4])
-    args = np.array(spec.args, dtype=np.float64)
-    if world > 1:
-        args[-1] = args[-1] * (1.0 + rank / world)
+    # outer parameter axis of `world` rows (the last parameter -- L for the hyperbolic model, as in
+    # BASELINE configs[4] -- scaled over [1, 2)); plan_shard hands every rank its block: one row
+    all_rows = np.tile(np.array(spec.args, dtype=np.float64), (world, 1))
+    all_rows[:, -1] *= 1.0 + np.arange(world) / world
+    plan = plan_shard(world, N0, world, rank)
+    assert plan.axis == "param" and plan.p_count == 1 and plan.row_count == N0
+    args = all_rows[plan.p_begin]
     out = torch.empty((N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
     stream = torch.cuda.current_stream().cuda_stream
     nbytes = out.numel() * 8
@@ -134,8 +164,9 @@ def main():
     achieved = BYTES_PER_POINT * points / (ms_kernel * 1e-3) / 1e9
 
     if rank == 0:
+        kernel = "inflx_sweep_rows_complete" if lib.stage_info["out_mask"] & 2 == 0 else "inflx_sweep_tile_complete"
         line = {
-            "metric": "grid-points/sec on complete_analysis sweep",
+            "metric": "grid-points/sec on complete_analysis sweep; achieved HBM GB/s vs peak",
             "value": world * points * opt.steps / elapsed,
             "unit": "grid-points/s",
             "n_gpus": world,
@@ -158,8 +189,8 @@ def main():
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": None,
-                "kernel": "inflx_sweep_rows_complete" if lib.stage_info["out_mask"] & 2 == 0 else "inflx_sweep_tile_complete",
+                "traffic": recorded_traffic(kernel, opt.model, opt.n),
+                "kernel": kernel,
                 "kernel_ms": ms_kernel,
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * points,
             },

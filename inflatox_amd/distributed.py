@@ -1,0 +1,131 @@
+"""Sharding of a sweep over the GPUs of one node (one process per GPU, torch.distributed).
+
+The reference has no distributed code at all: its only parallelism is rayon threads over grid
+points inside one process (src/anguelova.rs:524-540).  Every grid point and every parameter row is
+independent, so the sweep shards without any exchange on the data path:
+
+  * the outermost axis is split into contiguous, balanced blocks, one per rank -- the parameter axis
+    when there are at least as many parameter rows as ranks, the grid's row axis otherwise;
+  * each rank sweeps its block into its own HBM (``InflatoxDevLib.sweep_device``);
+  * only if the caller wants the whole result on every GPU is one ``all_gather`` issued
+    (RCCL over xGMI on GPUs, i.e. torch.distributed backend "nccl"; "gloo" on CPU tensors in tests).
+    The gather moves (world-1)/world of the result through each GPU's links and costs far more than
+    the sweep itself (Multi-GPU), which is why it is opt-in.
+
+The compute step is injected as a callable so that the partition/gather logic can be exercised on
+CPU ranks (tests/test_distributed.py uses the CPU oracle as the callable; the product passes the
+HIP sweep).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _native
+
+
+def block_bounds(n_items: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous balanced partition: the first ``n_items % world`` ranks get one item more."""
+    base, extra = divmod(n_items, world)
+    begin = rank * base + min(rank, extra)
+    return begin, base + (1 if rank < extra else 0)
+
+
+@dataclass(frozen=True)
+class ShardPlan:
+    axis: str  # "param" or "rows"
+    p_begin: int
+    p_count: int
+    row_begin: int
+    row_count: int
+
+    @property
+    def empty(self) -> bool:
+        return self.p_count == 0 or self.row_count == 0
+
+
+def plan_shard(P: int, N0: int, world: int, rank: int) -> ShardPlan:
+    """Which block of the (P, N0) outer index space does ``rank`` own?"""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError(f"rank {rank} outside world of size {world}")
+    if P >= world:
+        b, c = block_bounds(P, world, rank)
+        return ShardPlan("param", b, c, 0, N0)
+    b, c = block_bounds(N0, world, rank)
+    return ShardPlan("rows", 0, P, b, c)
+
+
+class ShardedSweep:
+    """Runs one rank's share of a (P parameter rows) x (N0 x N1 grid) sweep and optionally gathers it.
+
+    ``compute(p_rows, row_begin, row_count) -> array (p_count, row_count, N1, K)``: the local sweep.
+    ``HipCompute`` below is the product's implementation.
+    """
+
+    def __init__(self, compute, rank: int = 0, world: int = 1, process_group=None):
+        self.compute = compute
+        self.rank = rank
+        self.world = world
+        self.group = process_group
+
+    def run(self, args2d, N0: int, gather: bool = False):
+        """Returns ``(plan, local_block)`` or, with ``gather``, ``(plan, full)`` where ``full`` has the
+        shape (P, N0, N1, K) on every rank."""
+        import torch
+
+        args2d = np.atleast_2d(np.asarray(args2d, dtype=np.float64))
+        P = args2d.shape[0]
+        plan = plan_shard(P, N0, self.world, self.rank)
+        local = self.compute(args2d[plan.p_begin : plan.p_begin + plan.p_count], plan.row_begin, plan.row_count)
+        if not gather or self.world == 1:
+            return plan, local
+        import torch.distributed as dist
+
+        local_t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local))
+        # equal-sized contributions: pad every block to the largest one along the sharded axis
+        n_items = P if plan.axis == "param" else N0
+        biggest = block_bounds(n_items, self.world, 0)[1]
+        axis = 0 if plan.axis == "param" else 1
+        pad_shape = list(local_t.shape)
+        pad_shape[axis] = biggest
+        send = local_t.new_zeros(pad_shape)
+        send.narrow(axis, 0, local_t.shape[axis]).copy_(local_t)
+        recv = send.new_empty([self.world] + pad_shape)
+        # flat views: the one calling convention both RCCL ("nccl") and gloo accept
+        dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=self.group)
+        pieces = []
+        for r in range(self.world):
+            _, count = block_bounds(n_items, self.world, r)
+            pieces.append(recv[r].narrow(axis, 0, count))
+        return plan, torch.cat(pieces, dim=axis)
+
+
+class HipCompute:
+    """The product's local sweep: one ``inflx_sweep_device`` launch into a torch CUDA tensor."""
+
+    def __init__(self, devlib: _native.InflatoxDevLib, extent, N0: int, N1: int, op: int = _native.OP_COMPLETE):
+        self.lib = devlib
+        self.extent = extent
+        self.N0, self.N1, self.op = N0, N1, op
+
+    def __call__(self, p_rows, row_begin, row_count):
+        import torch
+
+        k = _native.OP_WIDTH[self.op]
+        out = torch.empty((len(p_rows), row_count, self.N1, k), dtype=torch.float64, device=f"cuda:{self.lib.device}")
+        if out.numel():
+            self.lib.sweep_device(
+                self.op,
+                p_rows,
+                out.data_ptr(),
+                out.numel() * 8,
+                self.extent,
+                self.N0,
+                self.N1,
+                row_begin=row_begin,
+                row_count=row_count,
+                stream=torch.cuda.current_stream(out.device).cuda_stream,
+            )
+        return out

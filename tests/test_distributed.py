@@ -1,0 +1,87 @@
+"""The N>1 path on CPU: two gloo ranks shard a sweep (parameter axis, then row axis), gather it, and
+the result must equal the single-process sweep.  The local compute step is the CPU oracle here; on
+GPUs it is the HIP sweep (inflatox_amd.distributed.HipCompute) -- the partition and gather logic under
+test is the same code."""
+
+import os
+import socket
+
+import numpy as np
+import pytest
+
+from inflatox_amd.distributed import ShardedSweep, block_bounds, plan_shard
+
+
+def test_block_bounds_cover_everything_once():
+    for n in (0, 1, 5, 8, 17, 512):
+        for world in (1, 2, 3, 8):
+            seen = []
+            for r in range(world):
+                b, c = block_bounds(n, world, r)
+                seen.extend(range(b, b + c))
+            assert seen == list(range(n))
+            sizes = [block_bounds(n, world, r)[1] for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes, reverse=True)
+
+
+def test_plan_prefers_parameter_axis():
+    p = plan_shard(P=512, N0=8192, world=8, rank=3)
+    assert (p.axis, p.p_begin, p.p_count, p.row_begin, p.row_count) == ("param", 192, 64, 0, 8192)
+    p = plan_shard(P=1, N0=8192, world=8, rank=7)
+    assert (p.axis, p.p_begin, p.p_count, p.row_begin, p.row_count) == ("rows", 0, 1, 7168, 1024)
+    with pytest.raises(ValueError):
+        plan_shard(4, 4, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, case, tmpdir):
+    import torch.distributed as dist
+
+    import oracle
+    from inflatox_amd import example_models, workloads
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        name, P, N0, N1 = case
+        spec = example_models.get(name)
+        src, _ = oracle.emit_c_source(workloads.model_for(name), **spec.compiler_kwargs)
+        om = oracle.OracleModel(oracle.compile_c_model(src))
+        args = np.stack([spec.args * (1.0 + 0.1 * k) for k in range(P)])
+
+        def compute(p_rows, row_begin, row_count):
+            # rows [row_begin, row_begin+row_count) of the N0 x N1 grid: the same points as a full sweep
+            x0a, x0b, x1a, x1b = spec.extent
+            dx0 = (x0b - x0a) / N0
+            block = np.zeros((len(p_rows), row_count, N1, 6))
+            pts = oracle.grid_points(spec.extent, N0, N1).reshape(N0, N1, 2)[row_begin : row_begin + row_count].reshape(-1, 2)
+            for k, p in enumerate(p_rows):
+                block[k] = om.trajectory_sweep(oracle.OP.COMPLETE, p, pts).reshape(row_count, N1, 6)
+            return block
+
+        plan, full = ShardedSweep(compute, rank, world).run(args, N0, gather=True)
+        want = np.stack([om.grid_sweep(oracle.OP.COMPLETE, p, spec.extent, N0, N1) for p in args])
+        assert tuple(full.shape) == want.shape, (full.shape, want.shape)
+        assert np.array_equal(full.numpy(), want, equal_nan=True)
+        plan2, local = ShardedSweep(compute, rank, world).run(args, N0, gather=False)
+        if plan2.axis == "param":
+            assert np.array_equal(local, want[plan2.p_begin : plan2.p_begin + plan2.p_count], equal_nan=True)
+        else:
+            assert np.array_equal(local, want[:, plan2.row_begin : plan2.row_begin + plan2.row_count], equal_nan=True)
+        open(os.path.join(tmpdir, f"ok_{rank}"), "w").write(plan.axis)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", [("hyperbolic", 3, 12, 10), ("doc", 1, 13, 9)], ids=["param-axis", "row-axis"])
+def test_two_gloo_ranks_shard_and_gather(case, tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    axes = {open(tmp_path / f"ok_{r}").read() for r in range(2)}
+    assert axes == ({"param"} if case[1] >= 2 else {"rows"})
