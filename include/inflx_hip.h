@@ -117,10 +117,13 @@ int inflx_sweep_device(inflx_model* model, int op, const double* p, size_t P, si
                        size_t row_count, int layout, void* stream);
 
 /* As inflx_sweep_device, `repeats` times back to back between two HIP events recorded on the
- * launch stream; returns the mean kernel-launch duration in milliseconds (synchronises). */
+ * launch stream; returns the mean duration of one sweep in milliseconds (synchronises).  A sweep of a
+ * model whose values do not depend on x[1] is two launches (per-row evaluation, then the store stream);
+ * with `dominant_only` != 0 only the dominant one -- the store stream -- is repeated and timed. */
 int inflx_sweep_device_timed(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
                              size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
-                             size_t row_count, int layout, void* stream, int repeats, float* ms_per_launch);
+                             size_t row_count, int layout, void* stream, int repeats, int dominant_only,
+                             float* ms_per_launch);
 
 /* wait for everything enqueued on the model's own stream */
 int inflx_synchronize(inflx_model* model);

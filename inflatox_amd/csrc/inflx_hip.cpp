@@ -17,6 +17,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -49,7 +50,6 @@ constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5};
 
 // device chunk used by the host-result path: two buffers of this many bytes at most
 constexpr size_t kChunkBytes = size_t(512) << 20;
-
 }  // namespace
 
 struct inflx_model {
@@ -60,12 +60,18 @@ struct inflx_model {
   hipFunction_t tile[INFLX_OP_COUNT] = {};
   hipFunction_t rows[INFLX_OP_COUNT] = {};
   hipFunction_t traj[INFLX_OP_COUNT] = {};
+  hipFunction_t rowvals[INFLX_OP_COUNT] = {};
+  hipFunction_t rowstream6 = nullptr;
+  double* d_row_table = nullptr;  // [P][rows][8] per-row results of the row-broadcast path
+  size_t d_row_table_cap = 0;
   InflxKernelInfo info = {};
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
   std::string name, path;
   double* d_params = nullptr;
   size_t d_params_cap = 0;
+  std::vector<double> params_on_device;  // what d_params currently holds (skips redundant uploads)
+  hipStream_t params_stream = nullptr;   // stream the last upload was ordered on
   void* d_chunk[2] = {nullptr, nullptr};
   size_t d_chunk_cap[2] = {0, 0};
   hipEvent_t chunk_done[2] = {nullptr, nullptr};
@@ -92,11 +98,20 @@ int ensure_params(inflx_model* m, const double* p, size_t count, hipStream_t s) 
   if (count > m->d_params_cap) {
     if (m->d_params) HIP_TRY(hipFree(m->d_params));
     m->d_params = nullptr;
+    m->params_on_device.clear();
     size_t cap = std::max<size_t>(count, 64);
     HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_params), cap * sizeof(double)));
     m->d_params_cap = cap;
   }
+  // a parameter sweep re-launches with the same rows far more often than it changes them; the upload
+  // (a synchronous staging copy for pageable memory) is skipped when the device copy is current and
+  // was last written on the same stream ordering domain (same stream)
+  if (m->params_on_device.size() == count && m->params_stream == s &&
+      memcmp(m->params_on_device.data(), p, count * sizeof(double)) == 0)
+    return INFLX_OK;
   HIP_TRY(hipMemcpyAsync(m->d_params, p, count * sizeof(double), hipMemcpyHostToDevice, s));
+  m->params_on_device.assign(p, p + count);
+  m->params_stream = s;
   return INFLX_OK;
 }
 
@@ -115,8 +130,20 @@ int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p
 }
 
 // Enqueue one sweep launch on `s`; `d_params` points at P parameter rows in device memory.
+int ensure_row_table(inflx_model* m, size_t doubles) {
+  if (doubles <= m->d_row_table_cap) return INFLX_OK;
+  if (m->d_row_table) HIP_TRY(hipFree(m->d_row_table));
+  m->d_row_table = nullptr;
+  m->d_row_table_cap = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_row_table), doubles * sizeof(double)));
+  m->d_row_table_cap = doubles;
+  return INFLX_OK;
+}
+
+// `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
+// 2 = only the store stream (used to time the dominant kernel on its own).
 int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
-                size_t row_begin, size_t row_count, int layout, hipStream_t s) {
+                size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0) {
   if (row_count == 0 || N1 == 0) return INFLX_OK;
   InflxSweepArgs a;
   memset(&a, 0, sizeof a);
@@ -136,14 +163,39 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   void* params[] = {&a};
   const bool row_uniform = (m->info.out_mask & 2u) == 0;
   if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
-  if (row_uniform) {
+  if (row_uniform && kOpWidth[op] == 6 && layout == INFLX_AOS) {
+    // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
+    // store per thread, 4 KiB per workgroup); `what` selects both (0), or one of them for timing
+    const size_t cpr = (3 * N1 + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
+    if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
+    // replicas of every row's table entry (see inflx_kernel_abi.h); fewer when the table would get large
+    size_t replicas = 32;
+    while (replicas > 1 && P * row_count * replicas * 64 > (size_t(1) << 30)) replicas /= 2;
+    replicas = std::min(replicas, cpr);
+    int rc = ensure_row_table(m, P * row_count * replicas * 8);
+    if (rc) return rc;
+    a.row_table = m->d_row_table;
+    a.table_replicas = (uint32_t)replicas;
+    if (what != 2)
+      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + m->info.tile_cols - 1) / m->info.tile_cols), (unsigned)P, 1,
+                                    m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+    if (what != 1) {
+      // grid = (pieces per row, rows, P); grid.y is limited to 65535, longer slabs take several launches
+      for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
+        a.stream_row0 = (uint32_t)r0;
+        const size_t nr = std::min<size_t>(65535, row_count - r0);
+        HIP_TRY(hipModuleLaunchKernel(m->rowstream6, (unsigned)cpr, (unsigned)nr, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params,
+                                      nullptr));
+      }
+    }
+  } else if (row_uniform) {
     const size_t rpb = m->info.rows_per_block;
     const size_t groups = (row_count + rpb - 1) / rpb;
     // few rows: split each row into column chunks until the grid can fill 256 CUs x 8 workgroups
     size_t chunks = 1;
     const size_t want = 4096;
     if (groups * P < want) {
-      const size_t units = (kOpWidth[op] == 6 && layout == INFLX_AOS) ? 3 * N1 / 192 : N1 / 64;
+      const size_t units = N1 / 64;
       chunks = std::min<size_t>(std::max<size_t>(units, 1), (want + groups * P - 1) / (groups * P));
     }
     if (groups * chunks > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid too large for one launch");
@@ -269,6 +321,15 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
         return bail(INFLX_ERR_SYMBOL);
       }
     }
+    const std::string rv = std::string("inflx_sweep_rowvals_") + kOpNames[op];
+    if (hipModuleGetFunction(&m->rowvals[op], m->module, rv.c_str()) != hipSuccess) {
+      fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s", artefact_path, rv.c_str());
+      return bail(INFLX_ERR_SYMBOL);
+    }
+  }
+  if (hipModuleGetFunction(&m->rowstream6, m->module, "inflx_sweep_rowstream6") != hipSuccess) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_sweep_rowstream6", artefact_path);
+    return bail(INFLX_ERR_SYMBOL);
   }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -303,6 +364,7 @@ void inflx_close(inflx_model* m) {
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->d_params) (void)hipFree(m->d_params);
+  if (m->d_row_table) (void)hipFree(m->d_row_table);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
   if (m->module) (void)hipModuleUnload(m->module);
@@ -347,7 +409,7 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
 
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                              const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream,
-                             int repeats, float* ms_per_launch) {
+                             int repeats, int dominant_only, float* ms_per_launch) {
   if (repeats <= 0 || !ms_per_launch) return fail(INFLX_ERR_ARG, "repeats must be positive and ms_per_launch non-NULL");
   // first call validates everything and uploads the parameters
   int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
@@ -356,7 +418,8 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipEventRecord(m->t0, s));
   for (int k = 0; k < repeats; ++k) {
-    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
+    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s,
+                     dominant_only ? 2 : 0);
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(m->t1, s));

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 3u
+#define INFLX_KERNEL_ABI 6u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -38,6 +38,13 @@ struct InflxSweepArgs {
   uint32_t P;
   uint32_t layout;      // InflxLayout
   uint32_t col_chunks;  // row kernels: number of column chunks a row is split into
+  uint32_t stream_row0; // inflx_sweep_rowstream6: slab row that blockIdx.y == 0 writes (launches cover <= 65535 rows)
+  // row-broadcast path: per-row results, [P][row_count][table_replicas][8] doubles (first K of 8 used).
+  // Every row's 64-byte entry is stored table_replicas times, on cache lines of its own, because the
+  // ~400 wavefronts that stream one grid row all fetch it with scalar loads at the same moment: served
+  // from a single line that fetch throttles the store stream to 5.1 TB/s, from 32 replicas it runs at 6.8.
+  double* row_table;
+  uint32_t table_replicas;
   uint32_t reserved;
 };
 
@@ -61,5 +68,7 @@ struct InflxKernelInfo {
   uint32_t out_mask;    // bit0: some model value depends on x[0]; bit1: on x[1]
   uint32_t tile_rows;   // rows per workgroup tile of the tile kernels
   uint32_t tile_cols;   // columns per workgroup tile (= threads per workgroup)
-  uint32_t rows_per_block;  // rows per workgroup of the row-broadcast kernels
+  uint32_t rows_per_block;  // rows per workgroup of the row-broadcast kernels (SoA / single-value results)
+  uint32_t row_chunk_units;  // 16-byte units each workgroup of inflx_sweep_rowstream6 writes (= its thread count)
+  uint32_t reserved;
 };

@@ -45,6 +45,15 @@
 #ifndef INFLX_NT_STORES
 #define INFLX_NT_STORES 1
 #endif
+// tile kernels: minimum wavefronts per SIMD the register allocator must leave room for
+// (second argument of __launch_bounds__; 512 registers per lane / this = the VGPR+AGPR cap)
+#ifndef INFLX_MIN_WAVES
+#define INFLX_MIN_WAVES 2
+#endif
+// tile kernels: keep the parameter-only (U) values in LDS instead of 2 VGPRs each
+#ifndef INFLX_U_IN_LDS
+#define INFLX_U_IN_LDS (INFLX_NU > 8)
+#endif
 
 static_assert(INFLX_DIM == 2, "the sweep kernels need a two-field model (Hesse2D, hesse_bindings.rs:203)");
 
@@ -70,7 +79,8 @@ INFLX_EXPORT uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
 INFLX_EXPORT char MODEL_NAME[] = INFLX_MODEL_NAME;
 INFLX_EXPORT char USE_GSL = 0;
 INFLX_EXPORT InflxKernelInfo INFLX_KERNEL_INFO = {
-    INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK};
+    INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK,
+    kThreads, 0};
 
 template <int OP>
 struct OpWidth {
@@ -133,8 +143,16 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 
   double A[kNP];
   load_params(a.params, p, A);
+#if INFLX_U_IN_LDS
+  // wave-uniform values: computed once per workgroup, every later use is an LDS broadcast read, so
+  // they cost no long-lived VGPRs (a uniform f64 cannot live in SGPRs: there is no scalar FP unit)
+  __shared__ double U[kNU];
+  if (tid == 0) inflx_stage_uniform(A, U);
+  __syncthreads();
+#else
   double U[kNU];
   inflx_stage_uniform(A, U);
+#endif
 
   const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
   const uint64_t j = col0 + tid;
@@ -208,11 +226,80 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 // ================================================================================================
 // row kernels: no model value depends on x[1]  ->  one evaluation per grid row, broadcast along it
 // ================================================================================================
+// one lane evaluates everything a grid row needs (U, R and P stages + the per-point operation)
+template <int OP>
+__device__ __forceinline__ void eval_row(const InflxSweepArgs& a, unsigned p, uint64_t row, double* o) {
+  double A[kNP];
+  load_params(a.params, p, A);
+  double U[kNU], R[kNR], C[kNC];
+  inflx_stage_uniform(A, U);
+  const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
+  inflx_stage_row(x0, A, U, R);
+  // by construction of the row kernels nothing below reads x1 or C
+  InflxModelValues mv;
+  inflx_stage_point(x0, a.x1a, A, U, R, C, mv);
+  apply_op<OP>(mv, o);
+}
+
+// Row-broadcast path for the AoS result of the 6-value operation, two launches:
+//
+//  1. inflx_sweep_rowvals_*: one lane per grid row evaluates the row's six values into row_table
+//     (8192 rows = 32 workgroups; latency-bound, a few microseconds).
+//  2. inflx_sweep_rowstream6: the output is one contiguous stream of 16-byte units in which every grid
+//     row is N1 copies of the same 48 bytes, i.e. unit u of a row holds value pair (u mod 3).  Every
+//     THREAD issues exactly ONE 16-byte store and every 256-thread workgroup writes 4 KiB of contiguous
+//     memory; workgroups are dispatched in address order, so the resident ones always cover one compact,
+//     advancing window of HBM.  Measured on MI355X for the 3.2 GB result (scripts/micro/store_bw.hip):
+//     this shape 6.8-6.9 TB/s, hipMemsetAsync 6.5, several stores per thread 5.2-5.9 (one wavefront per
+//     row, grid-stride chunks, 8-96 KiB per workgroup), non-temporal pairs of adjacent stores 2.1.
+//     The row's values arrive by scalar loads (the table address is workgroup-uniform).
+template <int OP>
+__device__ __forceinline__ void sweep_rowvals(const InflxSweepArgs& a) {
+  constexpr int K = OpWidth<OP>::K;
+  const uint64_t row = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned p = blockIdx.y;
+  if (row >= a.row_count) return;
+  double o[K];
+  eval_row<OP>(a, p, row, o);
+  double* t = a.row_table + ((uint64_t)p * a.row_count + row) * a.table_replicas * 8;
+  for (unsigned r = 0; r < a.table_replicas; ++r) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) t[r * 8 + k] = o[k];
+  }
+}
+
+__device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
+  // grid: x = 4 KiB piece within the grid row, y = grid row (relative to stream_row0), z = parameter row;
+  // no index arithmetic beyond multiply-add -- with one store per thread even a 64-bit division per
+  // workgroup (flat grid -> (row, piece)) costs 30 % of the bandwidth
+  const uint64_t units_row = 3 * a.N1;
+  const unsigned k = blockIdx.x;
+  const uint64_t row = (uint64_t)a.stream_row0 + blockIdx.y;
+  const unsigned p = blockIdx.z;
+  const uint64_t slab_row = (uint64_t)p * a.row_count + row;
+  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + k % a.table_replicas) * 8;
+  const uint64_t u = (uint64_t)k * kThreads + threadIdx.x;
+  // u mod 3 == (k + tid) mod 3 because 256 == 1 (mod 3)
+  const unsigned phase = (k % 3 + threadIdx.x) % 3;
+  // the six values are workgroup-uniform: fetch them with scalar loads.  (Left to itself the compiler
+  // selects the *address* per lane and issues divergent vector loads inside branches; the empty asm
+  // pins the values in SGPRs so that the selection below is three v_cndmask pairs.)
+  double t0 = t[0], t1 = t[1], t2 = t[2], t3 = t[3], t4 = t[4], t5 = t[5];
+  asm volatile("" : "+s"(t0), "+s"(t1), "+s"(t2), "+s"(t3), "+s"(t4), "+s"(t5));
+  const inflx_d2 v = {phase == 0 ? t0 : (phase == 1 ? t2 : t4), phase == 0 ? t1 : (phase == 1 ? t3 : t5)};
+  // non-temporal on purpose: a plain store stream of 3.2 GB sweeps the row table out of the Infinity
+  // Cache, every table fetch then goes to HBM and the stream drops to 5.0 TB/s; with nt stores the
+  // table stays cached and the stream runs at 6.7-6.8 TB/s (scripts/micro/store_bw.hip, variants G/H/P)
+  if (u < units_row) __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(a.out + slab_row * a.N1 * 6 + 2 * u));
+}
+static_assert(kThreads % 3 == 1, "the phase rule of sweep_rowstream6 needs kThreads == 1 (mod 3)");
+
 template <int OP>
 __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
   constexpr int K = OpWidth<OP>::K;
+  // every result shape except the 6-value AoS one (which takes rowvals + rowstream6): 8-byte stores,
+  // one wavefront per grid row
   __shared__ double vals[kRowsPerBlock][8];
-
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & (kWave - 1);
   const unsigned wave = tid / kWave;
@@ -222,17 +309,8 @@ __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
   const uint64_t row0 = group * kRowsPerBlock;
 
   if (tid < kRowsPerBlock && row0 + tid < a.row_count) {
-    double A[kNP];
-    load_params(a.params, p, A);
-    double U[kNU], R[kNR], C[kNC];
-    inflx_stage_uniform(A, U);
-    const double x0 = inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a);
-    inflx_stage_row(x0, A, U, R);
-    // by construction of this kernel nothing below reads x1 or C
-    InflxModelValues mv;
-    inflx_stage_point(x0, a.x1a, A, U, R, C, mv);
     double o[K];
-    apply_op<OP>(mv, o);
+    eval_row<OP>(a, p, row0 + tid, o);
 #pragma unroll
     for (int k = 0; k < K; ++k) vals[tid][k] = o[k];
   }
@@ -245,39 +323,15 @@ __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
     double v[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) v[k] = vals[rr][k];
-
-    if (K == 6 && a.layout == INFLX_LAYOUT_AOS) {
-      // The row is N1 copies of the same 48 bytes.  In 16-byte units u = 0 .. 3*N1-1 the content
-      // of unit u is pair (u mod 3); lane l issues units l, l+64, l+128, ... and 64 mod 3 == 1,
-      // so it cycles through three register pairs.
-      inflx_d2 pr[3];
+    const uint64_t per_chunk = ((a.N1 + a.col_chunks - 1) / a.col_chunks + kWave - 1) / kWave * kWave;
+    const uint64_t j_begin = (uint64_t)chunk * per_chunk;
+    const uint64_t j_end = j_begin + per_chunk < a.N1 ? j_begin + per_chunk : a.N1;
+    for (uint64_t j = j_begin + lane; j < j_end; j += kWave) {
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        const unsigned t = (lane + s) % 3;
-        pr[s] = inflx_d2{t == 0 ? v[0] : (t == 1 ? v[2] : v[4]), t == 0 ? v[1] : (t == 1 ? v[3] : v[5])};
-      }
-      const uint64_t units = 3 * a.N1;
-      // column chunking in multiples of 192 units keeps the rotation phase
-      const uint64_t per_chunk = ((units + a.col_chunks - 1) / a.col_chunks + 191) / 192 * 192;
-      const uint64_t u_begin = (uint64_t)chunk * per_chunk;
-      const uint64_t u_end = u_begin + per_chunk < units ? u_begin + per_chunk : units;
-      double* dst = a.out + ((uint64_t)p * a.row_count + row) * a.N1 * 6;
-      for (uint64_t u = u_begin + lane; u < u_end; u += 192) {
-        store_d2(dst + 2 * u, pr[0]);
-        if (u + 64 < u_end) store_d2(dst + 2 * (u + 64), pr[1]);
-        if (u + 128 < u_end) store_d2(dst + 2 * (u + 128), pr[2]);
-      }
-    } else {
-      const uint64_t per_chunk = ((a.N1 + a.col_chunks - 1) / a.col_chunks + kWave - 1) / kWave * kWave;
-      const uint64_t j_begin = (uint64_t)chunk * per_chunk;
-      const uint64_t j_end = j_begin + per_chunk < a.N1 ? j_begin + per_chunk : a.N1;
-      for (uint64_t j = j_begin + lane; j < j_end; j += kWave) {
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const uint64_t off = a.layout == INFLX_LAYOUT_SOA ? (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j
-                                                            : (((uint64_t)p * a.row_count + row) * a.N1 + j) * K + k;
-          store_d1(a.out + off, v[k]);
-        }
+      for (int k = 0; k < K; ++k) {
+        const uint64_t off = a.layout == INFLX_LAYOUT_SOA ? (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j
+                                                          : (((uint64_t)p * a.row_count + row) * a.N1 + j) * K + k;
+        store_d1(a.out + off, v[k]);
       }
     }
   }
@@ -310,15 +364,20 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
 
 // ---- entry points (looked up by name with hipModuleGetFunction) --------------------------------
 #define INFLX_DEFINE_KERNELS(NAME, OP)                                                                   \
-  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_tile_##NAME(const InflxSweepArgs a) { \
+  extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_##NAME(const InflxSweepArgs a) { \
     sweep_tile<OP>(a);                                                                                   \
   }                                                                                                      \
   extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rows_##NAME(const InflxSweepArgs a) { \
     if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rows<OP>(a);                                          \
   }                                                                                                      \
+  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowvals_##NAME(const InflxSweepArgs a) { \
+    if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rowvals<OP>(a);                                       \
+  }                                                                                                      \
   extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_traj_##NAME(const InflxTrajectoryArgs a) { \
     sweep_trajectory<OP>(a);                                                                             \
   }
+
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
 
 INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)
 INFLX_DEFINE_KERNELS(consistency, INFLX_OP_CONSISTENCY)
