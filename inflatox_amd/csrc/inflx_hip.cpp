@@ -169,16 +169,14 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     const size_t cpr = (3 * N1 + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
     if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
     // replicas of every row's table entry (see inflx_kernel_abi.h); fewer when the table would get large
-    size_t replicas = 32;
-    while (replicas > 1 && P * row_count * replicas * 64 > (size_t(1) << 30)) replicas /= 2;
-    replicas = std::min(replicas, cpr);
+    size_t replicas = 32;  // always a power of two (the evaluation kernel indexes with shifts)
+    while (replicas > 1 && (P * row_count * replicas * 64 > (size_t(1) << 30) || replicas > cpr)) replicas /= 2;
     int rc = ensure_row_table(m, P * row_count * replicas * 8);
     if (rc) return rc;
     a.row_table = m->d_row_table;
     a.table_replicas = (uint32_t)replicas;
     if (what != 2)
-      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + m->info.tile_cols - 1) / m->info.tile_cols), (unsigned)P, 1,
-                                    m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)P, 1, 64, 1, 1, 0, s, params, nullptr));
     if (what != 1) {
       // grid = (pieces per row, rows, P); grid.y is limited to 65535, longer slabs take several launches
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {

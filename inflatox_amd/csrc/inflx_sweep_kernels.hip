@@ -255,17 +255,32 @@ __device__ __forceinline__ void eval_row(const InflxSweepArgs& a, unsigned p, ui
 //     The row's values arrive by scalar loads (the table address is workgroup-uniform).
 template <int OP>
 __device__ __forceinline__ void sweep_rowvals(const InflxSweepArgs& a) {
+  // one wavefront per workgroup (launched with 64 threads): 64 grid rows, spread over as many CUs as
+  // possible because the evaluation is a ~750-instruction dependent chain per lane (latency-bound)
   constexpr int K = OpWidth<OP>::K;
-  const uint64_t row = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  __shared__ __attribute__((aligned(16))) double vals[kWave][8];
+  const unsigned lane = threadIdx.x;
+  const uint64_t row0 = (uint64_t)blockIdx.x * kWave;
   const unsigned p = blockIdx.y;
-  if (row >= a.row_count) return;
-  double o[K];
-  eval_row<OP>(a, p, row, o);
-  double* t = a.row_table + ((uint64_t)p * a.row_count + row) * a.table_replicas * 8;
-  for (unsigned r = 0; r < a.table_replicas; ++r) {
+  double o[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
+  if (row0 + lane < a.row_count) eval_row<OP>(a, p, row0 + lane, o);
 #pragma unroll
-    for (int k = 0; k < K; ++k) t[r * 8 + k] = o[k];
+  for (int k = 0; k < 8; ++k) vals[lane][k] = o[k];
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  // the 64 rows' table entries ([row][replica][8 doubles], replicas a power of two) are one contiguous
+  // region: write it with coalesced 16-byte stores instead of 2-KiB-strided ones
+  const uint64_t left = a.row_count - row0;
+  const unsigned nrows = left < (uint64_t)kWave ? (unsigned)left : (unsigned)kWave;
+  const unsigned shift = 31 - __builtin_clz(a.table_replicas * 4);  // log2(units per row)
+  const unsigned units = nrows << shift;
+  inflx_d2* dst = reinterpret_cast<inflx_d2*>(a.row_table + ((uint64_t)p * a.row_count + row0) * a.table_replicas * 8);
+  for (unsigned q = lane; q < units; q += kWave) {
+    const unsigned r = q >> shift, part = q & 3;
+    dst[q] = *reinterpret_cast<const inflx_d2*>(&vals[r][2 * part]);
   }
+  (void)K;
 }
 
 __device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
