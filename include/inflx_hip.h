@@ -93,6 +93,11 @@ int inflx_consistency_rapidturn_only(inflx_model* model, const double* p, size_t
 int inflx_epsilon_v_only(inflx_model* model, const double* p, size_t n_p, double* out, const double* start_stop,
                          size_t N0, size_t N1, int progress, size_t threads); /* anguelova.rs:359-447 */
 
+/* flag_quantum_dif_py (src/anguelova.rs:574-626): out is a (N0,N1) array of bytes (numpy bool), 1 where
+ * every component of the normalised potential gradient (basis vector `v`) is <= accuracy */
+int inflx_flag_quantum_dif(inflx_model* model, const double* p, size_t n_p, uint8_t* out, const double* start_stop,
+                           size_t N0, size_t N1, int progress, double accuracy);
+
 /* on-trajectory variants (src/anguelova.rs:633-977): x is (n,2), out is (n,K) */
 int inflx_sweep_on_trajectory(inflx_model* model, int op, const double* p, size_t n_p, const double* x, size_t n,
                               double* out, int progress, size_t threads);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "inflx_consistency_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
     "inflx_consistency_rapidturn_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
     "inflx_epsilon_v_only": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_flag_quantum_dif": (C.c_int, [C.c_void_p, _DP, _SIZE, C.POINTER(C.c_uint8), _DP, _SIZE, _SIZE, C.c_int, C.c_double]),
     "inflx_sweep_on_trajectory": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _DP, _SIZE, _DP, C.c_int, _SIZE]),
     "inflx_sweep_host": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int]),
     "inflx_sweep_device": (
@@ -218,6 +219,20 @@ class InflatoxDevLib:
 
     def epsilon_v_only(self, p, out, start_stop, progress=False, threads=0):
         self._grid(self._lib.inflx_epsilon_v_only, p, out, start_stop, progress, threads, None)
+
+    def flag_quantum_dif(self, p, out, start_stop, progress=False, accuracy=1e-3):
+        """libinflx_rs.flag_quantum_dif_py(lib, p, x, start_stop, progress, accuracy), anguelova.rs:574."""
+        p = _f64(p, "p").reshape(-1)
+        ss = _f64(start_stop, "start_stop")
+        if ss.shape != (2, 2):
+            raise InflatoxShapeError(f"start_stop array should have 2 rows and as many columns as there are fields (got {ss.shape})")
+        if out.dtype != np.bool_ or out.ndim != 2 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("output array must be a writeable C-contiguous 2-D bool array")
+        _check(
+            self._lib.inflx_flag_quantum_dif(
+                self._h, _ptr(p), p.size, out.view(np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(ss), out.shape[0], out.shape[1], int(bool(progress)), float(accuracy)
+            )
+        )
 
     def sweep_on_trajectory(self, op, p, x, progress=False, threads=0) -> np.ndarray:
         p = _f64(p, "p").reshape(-1)

@@ -306,11 +306,14 @@ class Compiler:
         self.symbol_dict, params = self._number_parameters()
         if not self.silent and self.cse:
             print("Converting sympy to HIP using common subexpression elimination...")
-        cse = None
+        cse = cse_vector = None
         if self.cse:
-            # exactly the reference's per-function call (compiler.py:403-404)
+            # exactly the reference's per-function calls (compiler.py:403-404 and :425-426)
             def cse(expr):
                 return sympy.cse(expr, symbols=self._cse_symbols(), order="none", list=False)
+
+            def cse_vector(vector):
+                return sympy.cse(list(vector), symbols=self._cse_symbols(), list=True)
 
         text, info = emit_stage_header(
             self.symbolic_out,
@@ -321,6 +324,7 @@ class Compiler:
             __abi_version__,
             staged=self.staged,
             cse=cse,
+            cse_vector=cse_vector,
             regroup=self.regroup,
         )
         self.stage_info = info

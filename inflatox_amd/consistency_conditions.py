@@ -110,6 +110,13 @@ class GeneralisedAL(InflationCondition):
     def consistency_rapidturn(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000, progress=True, threads=None) -> np.ndarray:
         return self._single(self.dylib.consistency_rapidturn_only, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads)
 
+    def flag_quantum_dif(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=10_000, N_x1=10_000, progress=True, accuracy=1e-3) -> np.ndarray:
+        """Boolean (N_x0, N_x1) array: True where both components of the normalised potential gradient
+        are <= ``accuracy`` (reference consistency_conditions.py:477-523, src/anguelova.rs:166-170)."""
+        x = np.zeros((N_x0, N_x1), dtype=bool)
+        self.dylib.flag_quantum_dif(args, x, _start_stop(x0_start, x0_stop, x1_start, x1_stop), progress, accuracy)
+        return x
+
     # ---- on-trajectory variants (reference :529-715) ---------------------------------------------
     def complete_analysis_ot(self, args, x, progress=True, threads=None):
         threads = threads if threads is not None else 1

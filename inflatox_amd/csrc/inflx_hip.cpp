@@ -45,8 +45,10 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr uint16_t kAbiMajor = 5, kAbiMinor = 0;  // src/lib.rs:50 V_INFLX_ABI
-const char* const kOpNames[INFLX_OP_COUNT] = {"complete", "consistency", "rapidturn", "epsilon_v", "raw"};
-constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5};
+const char* const kOpNames[INFLX_OP_COUNT] = {"complete", "consistency", "rapidturn", "epsilon_v", "raw", "qdif"};
+constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5, 1};
+// bytes per grid point of an operation's result (the flag sweep writes one bool per point)
+constexpr size_t kOpBytes[INFLX_OP_COUNT] = {48, 8, 8, 8, 40, 1};
 
 // device chunk used by the host-result path: two buffers of this many bytes at most
 constexpr size_t kChunkBytes = size_t(512) << 20;
@@ -143,7 +145,7 @@ int ensure_row_table(inflx_model* m, size_t doubles) {
 // `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
 // 2 = only the store stream (used to time the dominant kernel on its own).
 int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
-                size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0) {
+                size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0, double accuracy = 0.0) {
   if (row_count == 0 || N1 == 0) return INFLX_OK;
   InflxSweepArgs a;
   memset(&a, 0, sizeof a);
@@ -160,8 +162,10 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   a.P = (uint32_t)P;
   a.layout = (uint32_t)layout;
   a.col_chunks = 1;
+  a.accuracy = accuracy;
   void* params[] = {&a};
-  const bool row_uniform = (m->info.out_mask & 2u) == 0;
+  // the flag sweep reads the basis vector, whose axis dependence the out_mask does not describe
+  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
   if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
   if (row_uniform && kOpWidth[op] == 6 && layout == INFLX_AOS) {
     // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
@@ -397,7 +401,8 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   if (!d_out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
   if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
-  const size_t need = P * row_count * N1 * kOpWidth[op] * sizeof(double);
+  if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
+  const size_t need = P * row_count * N1 * kOpBytes[op];
   if (d_out_bytes < need) return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, need);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
@@ -428,8 +433,13 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   return INFLX_OK;
 }
 
-int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
-                     size_t N1, size_t row_begin, size_t row_count, int layout) {
+}  // extern "C"
+
+namespace {
+// host-result sweep for every operation; `out` holds kOpBytes[op] bytes per grid point
+int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
+                    size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy) {
+  char* const out = static_cast<char*>(out_v);
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
   if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
@@ -440,7 +450,7 @@ int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n
   if ((rc = ensure_params(m, p, P * n_p, m->stream))) return rc;
 
   const size_t K = kOpWidth[op];
-  const size_t row_bytes = N1 * K * sizeof(double);
+  const size_t row_bytes = N1 * kOpBytes[op];
   // rows per chunk: whole rows of ONE parameter row at a time (keeps every copy contiguous in the
   // AoS result; the SoA result is copied plane by plane)
   size_t rows_per_chunk = std::max<size_t>(1, kChunkBytes / row_bytes);
@@ -459,16 +469,16 @@ int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n
       const size_t nrows = std::min(rows_per_chunk, row_count - r);
       if (used[b]) HIP_TRY(hipStreamWaitEvent(m->stream, m->copy_done[b], 0));
       rc = launch_grid(m, op, m->d_params + pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + r, nrows, layout,
-                       m->stream);
+                       m->stream, 0, accuracy);
       if (rc) return rc;
       HIP_TRY(hipEventRecord(m->chunk_done[b], m->stream));
       HIP_TRY(hipStreamWaitEvent(m->copy_stream, m->chunk_done[b], 0));
       if (layout == INFLX_AOS || K == 1) {
-        double* dst = out + (pr * row_count + r) * N1 * K;
+        char* dst = out + (pr * row_count + r) * row_bytes;
         HIP_TRY(hipMemcpyAsync(dst, m->d_chunk[b], nrows * row_bytes, hipMemcpyDeviceToHost, m->copy_stream));
       } else {
         for (size_t k = 0; k < K; ++k) {
-          double* dst = out + ((pr * K + k) * row_count + r) * N1;
+          char* dst = out + ((pr * K + k) * row_count + r) * N1 * sizeof(double);
           const double* src = static_cast<const double*>(m->d_chunk[b]) + k * nrows * N1;
           HIP_TRY(hipMemcpyAsync(dst, src, nrows * N1 * sizeof(double), hipMemcpyDeviceToHost, m->copy_stream));
         }
@@ -480,6 +490,22 @@ int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n
   HIP_TRY(hipStreamSynchronize(m->copy_stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return INFLX_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
+                     size_t N1, size_t row_begin, size_t row_count, int layout) {
+  if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
+  return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, 0.0);
+}
+
+int inflx_flag_quantum_dif(inflx_model* m, const double* p, size_t n_p, uint8_t* out, const double* ss, size_t N0, size_t N1,
+                           int progress, double accuracy) {
+  if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
+  if (progress) say("Calculating zeros of the potential gradient on HIP device %d.", m ? m->device : -1);
+  return sweep_host_impl(m, INFLX_OP_QDIF, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, accuracy);
 }
 
 int inflx_complete_analysis(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
@@ -503,6 +529,7 @@ int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_
                               int progress, size_t /*threads*/) {
   int rc = validate(m, op, p, 1, n_p);
   if (rc) return rc;
+  if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has no on-trajectory variant in the reference");
   if (n == 0) return INFLX_OK;
   if (!x || !out) return fail(INFLX_ERR_ARG, "trajectory / output pointer is NULL");
   HIP_TRY(hipSetDevice(m->device));

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 6u
+#define INFLX_KERNEL_ABI 7u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -12,7 +12,8 @@ enum InflxOp {
   INFLX_OP_RAPIDTURN = 2,    // ops::consistency_rapidturn_only 1 f64
   INFLX_OP_EPSILON_V = 3,    // ops::epsilon_v_only             1 f64
   INFLX_OP_RAW = 4,          // V, v00, v10, v11, |dV|^2        5 f64 (diagnostic; pins the model functions)
-  INFLX_OP_COUNT = 5
+  INFLX_OP_QDIF = 5,         // ops::flag_quantum_diff          1 byte (bool) per point
+  INFLX_OP_COUNT = 6
 };
 
 // output memory layout for multi-value operations
@@ -46,6 +47,7 @@ struct InflxSweepArgs {
   double* row_table;
   uint32_t table_replicas;
   uint32_t reserved;
+  double accuracy;  // INFLX_OP_QDIF: threshold of ops::flag_quantum_diff
 };
 
 // Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch
@@ -57,6 +59,7 @@ struct InflxTrajectoryArgs {
   uint64_t n;
   uint32_t P;
   uint32_t reserved;
+  double accuracy;
 };
 
 // Read by the host from the code object's INFLX_KERNEL_INFO global after loading it.

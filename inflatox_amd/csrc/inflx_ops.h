@@ -14,6 +14,8 @@ struct InflxModelValues {
   double v10;  // Hesse component along (w, v)     (C symbol `v10`, Hesse2D::v10 = fns[2])
   double v11;  // Hesse component along (w, w)     (C symbol `v11`)
   double g;    // |grad V|^2                       (C symbol `grad_norm_squared`)
+  double b0;   // basis vector v, component 0      (C symbol `v`, v_out[0]; Potential::grad)
+  double b1;   // basis vector v, component 1      (v_out[1])
 };
 
 INFLX_FN double inflx_sq(double x) {
@@ -67,6 +69,12 @@ INFLX_FN double inflx_op_consistency_only(const InflxModelValues& m) {
   const double lhs = m.v11 / m.V - 3.;
   const double rhs = 3. * inflx_sq(m.v00 / m.v10) + (m.v00 / m.V) * inflx_sq(m.v10 / m.v00);
   return fabs(fabs(lhs) - fabs(rhs)) / (fabs(lhs) + fabs(rhs));
+}
+
+// ops::flag_quantum_diff, src/anguelova.rs:166-170: all components of the normalised gradient
+// <= accuracy (no abs(); a NaN component makes the flag false, as in Rust)
+INFLX_FN bool inflx_op_flag_quantum_diff(const InflxModelValues& m, double accuracy) {
+  return (m.b0 <= accuracy) && (m.b1 <= accuracy);
 }
 
 // index -> field-space coordinate, src/anguelova.rs:514-516,531-533: (idx as f64) * spacing + offset,

@@ -88,8 +88,10 @@ struct OpWidth {
 };
 
 template <int OP>
-__device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o) {
-  if constexpr (OP == INFLX_OP_COMPLETE) {
+__device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, [[maybe_unused]] double accuracy = 0.0) {
+  if constexpr (OP == INFLX_OP_QDIF) {
+    o[0] = inflx_op_flag_quantum_diff(mv, accuracy) ? 1.0 : 0.0;
+  } else if constexpr (OP == INFLX_OP_COMPLETE) {
     inflx_op_complete_analysis(mv, o);
   } else if constexpr (OP == INFLX_OP_CONSISTENCY) {
     o[0] = inflx_op_consistency_only(mv);
@@ -112,6 +114,21 @@ __device__ __forceinline__ void store_d2(double* p, inflx_d2 v) {
 #else
   *reinterpret_cast<inflx_d2*>(p) = v;
 #endif
+}
+
+// one scalar result at element offset `off`: an f64, or for the boolean flag sweep one byte
+// (the reference fills a numpy bool array, consistency_conditions.py:515)
+template <int OP>
+__device__ __forceinline__ void store_scalar(double* out, uint64_t off, double v) {
+  if constexpr (OP == INFLX_OP_QDIF) {
+    reinterpret_cast<uint8_t*>(out)[off] = v != 0.0 ? 1 : 0;
+  } else {
+#if INFLX_NT_STORES
+    __builtin_nontemporal_store(v, out + off);
+#else
+    out[off] = v;
+#endif
+  }
 }
 
 __device__ __forceinline__ void store_d1(double* p, double v) {
@@ -181,14 +198,14 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     InflxModelValues mv;
     inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
     double o[K];
-    apply_op<OP>(mv, o);
+    apply_op<OP>(mv, o, a.accuracy);
 
     if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
       if (in_range) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
           const uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j;
-          store_d1(a.out + off, o[k]);
+          store_scalar<OP>(a.out, off, o[k]);
         }
       }
     } else if constexpr (K == 6) {
@@ -238,7 +255,7 @@ __device__ __forceinline__ void eval_row(const InflxSweepArgs& a, unsigned p, ui
   // by construction of the row kernels nothing below reads x1 or C
   InflxModelValues mv;
   inflx_stage_point(x0, a.x1a, A, U, R, C, mv);
-  apply_op<OP>(mv, o);
+  apply_op<OP>(mv, o, a.accuracy);
 }
 
 // Row-broadcast path for the AoS result of the 6-value operation, two launches:
@@ -346,7 +363,7 @@ __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
       for (int k = 0; k < K; ++k) {
         const uint64_t off = a.layout == INFLX_LAYOUT_SOA ? (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j
                                                           : (((uint64_t)p * a.row_count + row) * a.N1 + j) * K + k;
-        store_d1(a.out + off, v[k]);
+        store_scalar<OP>(a.out, off, v[k]);
       }
     }
   }
@@ -371,10 +388,9 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   InflxModelValues mv;
   inflx_stage_point(x0, x1, A, U, R, C, mv);
   double o[K];
-  apply_op<OP>(mv, o);
-  double* dst = a.out + ((uint64_t)p * a.n + idx) * K;
+  apply_op<OP>(mv, o, a.accuracy);
 #pragma unroll
-  for (int k = 0; k < K; ++k) dst[k] = o[k];
+  for (int k = 0; k < K; ++k) store_scalar<OP>(a.out, ((uint64_t)p * a.n + idx) * K + k, o[k]);
 }
 
 // ---- entry points (looked up by name with hipModuleGetFunction) --------------------------------
@@ -399,3 +415,4 @@ INFLX_DEFINE_KERNELS(consistency, INFLX_OP_CONSISTENCY)
 INFLX_DEFINE_KERNELS(rapidturn, INFLX_OP_RAPIDTURN)
 INFLX_DEFINE_KERNELS(epsilon_v, INFLX_OP_EPSILON_V)
 INFLX_DEFINE_KERNELS(raw, INFLX_OP_RAW)
+INFLX_DEFINE_KERNELS(qdif, INFLX_OP_QDIF)

@@ -43,7 +43,7 @@ from sympy.printing.precedence import PRECEDENCE, precedence
 U, R, C, P = 0, 1, 2, 3
 STAGE_PREFIX = {U: "u", R: "r", C: "c", P: "p"}
 ARRAY = {U: "U", R: "R", C: "C"}
-OUTPUT_FIELDS = ("V", "v00", "v10", "v11", "g")
+OUTPUT_FIELDS = ("V", "v00", "v10", "v11", "g", "b0", "b1")
 
 
 def split_product(expr):
@@ -227,7 +227,8 @@ class Stager:
     """
 
     def __init__(self, functions, x0, x1, names, staged=True, regroup=False):
-        """``functions``: one ``(replacements, expression)`` pair per model value, where
+        """``functions``: one ``(replacements, [expressions])`` pair per generated C function of the
+        reference (five scalar functions and the two-component basis vector ``v``), where
         ``replacements`` is the (possibly empty) list of ``(symbol, definition)`` pairs the
         reference's per-function ``sympy.cse`` produced; those symbols are local to their function."""
         sys.setrecursionlimit(max(sys.getrecursionlimit(), 50000))
@@ -248,24 +249,26 @@ class Stager:
         # symbols exist (a node mentioning `cse3` means something else in every function)
         share_across = all(not repl for repl, _ in functions)
         if share_across:
-            self._count_refs([e for _, e in functions])
+            self._count_refs([e for _, exprs in functions for e in exprs])
         self.outputs, self.out_masks = [], []
-        for repl, expr in functions:
+        for repl, exprs in functions:
             if not share_across:
                 self.named, self._mask, self.refs, self.local = {}, {}, Counter(), {}
-                self._count_refs([d for _, d in repl] + [expr])
+                self._count_refs([d for _, d in repl] + list(exprs))
             for sym, definition in repl:
                 m = self.mask(definition) if staged else P
                 self._ctx = m
                 self.local[sym] = (self._variable(definition, m, reference=False), m)
-            self._ctx = P
-            self.out_masks.append(self.mask(expr) if staged else P)
-            text = self.value(expr)
-            if text in self.stage_of:
-                self.used_by[text].add("out")
-            self.outputs.append(text)
+            for expr in exprs:
+                self._ctx = P
+                self.out_masks.append(self.mask(expr) if staged else P)
+                text = self.value(expr)
+                if text in self.stage_of:
+                    self.used_by[text].add("out")
+                self.outputs.append(text)
+        # the axis mask that selects the row-broadcast kernels covers the five values the sweeps use
         self.out_mask = 0
-        for m in self.out_masks:
+        for m in self.out_masks[:5]:
             self.out_mask |= m
         self.exports = {m: [n for n, s in self.stage_of.items() if s == m and (self.used_by[n] - {m})] for m in (U, R, C)}
 
@@ -398,13 +401,14 @@ class Stager:
 
 
 def emit_stage_header(
-    model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, regroup: bool = False
+    model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False
 ):
     """Return (header text, info dict) for the model.
 
     ``cse``: ``None``, or a callable ``expr -> (replacements, reduced)`` reproducing the reference's
     per-function ``sympy.cse`` call (compiler.py:403-410); when given, the reference evaluates the
-    cse'd form, so that form -- not the plain expression -- is what gets staged."""
+    cse'd form, so that form -- not the plain expression -- is what gets staged.  ``cse_vector``
+    is the list-valued variant the reference uses for the basis vectors (compiler.py:425-433)."""
     x0, x1 = model.coordinates
     exprs = [
         sympy.sympify(model.potential),
@@ -413,16 +417,24 @@ def emit_stage_header(
         sympy.sympify(model.hesse_cmp[1][1]),
         sympy.sympify(model.gradient_square),
     ]
+    basis_v = [sympy.sympify(c) for c in model.basis[0]]  # the C function `v` (Potential::grad)
     tangents = set(model.coordinate_tangents)
-    for e in exprs:
+    for e in exprs + basis_v:
         if e.free_symbols & tangents:
             raise Exception("potential / Hesse expressions may not depend on field velocities")
 
     plain = C99CodePrinter()._print_Symbol
     names = {x0: "x0", x1: "x1"}
-    for sym in set().union(*[e.free_symbols for e in exprs]) - {x0, x1}:
+    for sym in set().union(*[e.free_symbols for e in exprs + basis_v]) - {x0, x1}:
         names[sym] = param_slots[plain(sym)]
-    functions = [cse(e) if cse is not None else ([], e) for e in exprs]
+    functions = []
+    for e in exprs:
+        if cse is not None:
+            repl, red = cse(e)
+            functions.append((repl, [red]))
+        else:
+            functions.append(([], [e]))
+    functions.append(cse_vector(basis_v) if cse_vector is not None else ([], basis_v))
     st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup)
 
     idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}

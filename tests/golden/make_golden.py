@@ -179,6 +179,8 @@ def main(models):
             out[f"{tag}_consistency"] = om.grid_sweep(OP.CONSISTENCY, spec.args, ext, n0, n1)
             out[f"{tag}_rapidturn"] = om.grid_sweep(OP.RAPIDTURN, spec.args, ext, n0, n1)
             out[f"{tag}_epsilon_v"] = om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1)
+            for accuracy in (1e-3, 0.5, 0.9):  # ops::flag_quantum_diff through the reference's C function `v`
+                out[f"{tag}_qdif_{accuracy}"] = om.grid_sweep(OP.QDIF, spec.args, ext, n0, n1, accuracy=accuracy)
             if tag in ("g16", "g64"):
                 out[f"{tag}_raw_mp"] = mp_truth(model, comp.symbol_dict, spec.args, ext, n0, n1)
         if name == "doc":

@@ -37,8 +37,10 @@ static constexpr int kNC = INFLX_NC > 0 ? INFLX_NC : 1;
 
 static int width(int op) { return op == INFLX_OP_COMPLETE ? 6 : (op == INFLX_OP_RAW ? 5 : 1); }
 
+static double g_accuracy = 0.0;
 static void apply(int op, const InflxModelValues& mv, double* o) {
   switch (op) {
+    case INFLX_OP_QDIF: o[0] = inflx_op_flag_quantum_diff(mv, g_accuracy) ? 1.0 : 0.0; break;
     case INFLX_OP_COMPLETE: inflx_op_complete_analysis(mv, o); break;
     case INFLX_OP_CONSISTENCY: o[0] = inflx_op_consistency_only(mv); break;
     case INFLX_OP_RAPIDTURN: o[0] = inflx_op_consistency_rapidturn_only(mv); break;
@@ -51,6 +53,7 @@ static void apply(int op, const InflxModelValues& mv, double* o) {
 extern "C" {
 
 unsigned twin_n_parameters() { return INFLX_N_PARAMETERS; }
+void twin_set_accuracy(double a) { g_accuracy = a; }
 unsigned twin_out_mask() { return INFLX_OUT_MASK; }
 
 // out: (N0, N1, K) AoS

@@ -33,12 +33,16 @@ class HostTwin:
         self.lib = C.CDLL(so)
         self.lib.twin_grid.argtypes = [C.c_int, _DP, _DP, C.c_size_t, C.c_size_t, _DP]
         self.lib.twin_trajectory.argtypes = [C.c_int, _DP, _DP, C.c_size_t, _DP]
+        self.lib.twin_set_accuracy.argtypes = [C.c_double]
         self.n_parameters = self.lib.twin_n_parameters()
         self.out_mask = self.lib.twin_out_mask()
 
     @staticmethod
     def _w(op):
         return {0: 6, 4: 5}.get(op, 1)
+
+    def set_accuracy(self, accuracy: float):
+        self.lib.twin_set_accuracy(accuracy)
 
     def grid(self, op, p, extent, n0, n1):
         p = np.ascontiguousarray(p, dtype=np.float64)

@@ -225,3 +225,21 @@ def test_full_size_sampled_against_oracle(name, n, gpu_lib):
     raw = om.trajectory_sweep(OP.RAW, spec.args, pts)
     got = out[torch.as_tensor(ii, device="cuda:0"), torch.as_tensor(jj, device="cuda:0")].cpu().numpy()
     judge(name, spec.args, pts, (4000,), raw, got, want, tol.epilogue, f"{name}/{n} sampled")
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_flag_quantum_dif(name, gpu_lib):
+    """GeneralisedAL.flag_quantum_dif vs the oracle (ops::flag_quantum_diff, src/anguelova.rs:166-170,574-626)."""
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    spec, art, lib = devlib(name, gpu_lib)
+    om, _ = oracle_model(name)
+    al = GeneralisedAL(art)
+    n0, n1 = 130, 333
+    for accuracy in (1e-3, 0.5, 0.9):
+        got = al.flag_quantum_dif(spec.args, *spec.extent, n0, n1, progress=False, accuracy=accuracy)
+        assert got.dtype == np.bool_ and got.shape == (n0, n1)
+        want = om.grid_sweep(OP.QDIF, spec.args, spec.extent, n0, n1, accuracy=accuracy)
+        # a gradient component within a few ulps of the threshold may flip; nothing else may
+        assert (got != want).mean() <= 0.002, (name, accuracy, int((got != want).sum()))
+    assert got.any() or not want.any()
