@@ -110,7 +110,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != opt.gpus:
         raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {opt.gpus}")
-    distributed = world > 1
+    # INFLX_BENCH_FORCE_DIST=1 exercises the process-group path (init, barrier, MAX) with a single rank
+    distributed = world > 1 or os.environ.get("INFLX_BENCH_FORCE_DIST") == "1"
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist

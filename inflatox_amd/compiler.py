@@ -205,6 +205,8 @@ class Compiler:
         "-Werror",
         "-Wno-unused-but-set-variable",
         "-Wno-unused-variable",
+        # a model with very many row-stage values may not reach the requested occupancy: a remark, not an error
+        "-Wno-error=pass-failed",
     ]
 
     def __init__(

@@ -17,7 +17,7 @@ stream = torch.cuda.current_stream().cuda_stream
 out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
 for name in models:
     spec = example_models.get(name)
-    for waves, ulds, rows in itertools.product((1, 2, 3, 4), (0, 1), (32,)):
+    for waves, ulds, rows in itertools.product((2,), (0, 1), (32, 64, 128)):
         flags = Compiler.default_hipcc_flags + [f"-DINFLX_MIN_WAVES={waves}", f"-DINFLX_U_IN_LDS={ulds}", f"-DINFLX_TILE_ROWS={rows}"]
         try:
             art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, **spec.compiler_kwargs).compile()
