@@ -159,6 +159,26 @@ def test_row_kernel_layouts_and_chunks(gpu_lib):
         compare(eps, om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1), 1e-10, "hyperbolic/eps")
 
 
+def test_row_path_row_ranges_and_batches(gpu_lib):
+    """The two-launch row-broadcast path with a row offset (multi-GPU row sharding) and P > 1."""
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    ext = (-0.9, 1.3, 0.1, 2.0)
+    n0, n1 = 150, 257
+    full = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, n0, n1)
+    part = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, n0, n1, row_begin=37, row_count=101)
+    assert np.array_equal(part, full[37:138], equal_nan=True)
+    P = np.stack([spec.args, spec.args * np.array([1.0, 0.5, 2.0]), spec.args * np.array([2.0, 1.0, 0.7])])
+    batch = lib.sweep_host(gpu_lib.OP_COMPLETE, P, ext, n0, n1)
+    for k in range(3):
+        assert np.array_equal(batch[k], lib.sweep_host(gpu_lib.OP_COMPLETE, P[k], ext, n0, n1), equal_nan=True)
+    import torch
+
+    out = torch.empty((3, 101, n1, 6), dtype=torch.float64, device="cuda:0")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, P, out.data_ptr(), out.numel() * 8, ext, n0, n1, row_begin=37, row_count=101, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), batch[:, 37:138], equal_nan=True)
+
+
 def test_trajectory_variants(gpu_lib):
     rng = np.random.default_rng(7)
     for name in ("doc", "angular"):
