@@ -99,6 +99,7 @@ struct inflx_model {
   hipFunction_t traj[INFLX_OP_COUNT] = {};
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
+  hipFunction_t rowstream_planes = nullptr;
   double* d_row_table = nullptr;  // [P][rows][8] per-row results of the row-broadcast path
   size_t d_row_table_cap = 0;
   InflxKernelInfo info = {};
@@ -202,10 +203,13 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   // the flag sweep reads the basis vector, whose axis dependence the out_mask does not describe
   const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
   if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
-  if (row_uniform && kOpWidth[op] == 6 && layout == INFLX_AOS) {
+  const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
+  const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0 && P * kOpWidth[op] <= 65535;
+  if (row_uniform && (aos6 || planes)) {
     // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
     // store per thread, 4 KiB per workgroup); `what` selects both (0), or one of them for timing
-    const size_t cpr = (3 * N1 + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
+    const size_t units_row = aos6 ? 3 * N1 : N1 / 2;
+    const size_t cpr = (units_row + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
     if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
     // replicas of every row's table entry (see inflx_kernel_abi.h); fewer when the table would get large
     size_t replicas = 32;  // always a power of two (the evaluation kernel indexes with shifts)
@@ -214,15 +218,16 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     if (rc) return rc;
     a.row_table = m->d_row_table;
     a.table_replicas = (uint32_t)replicas;
+    a.stream_planes = (uint32_t)kOpWidth[op];
     if (what != 2)
       HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)P, 1, 64, 1, 1, 0, s, params, nullptr));
     if (what != 1) {
-      // grid = (pieces per row, rows, P); grid.y is limited to 65535, longer slabs take several launches
+      // grid.y is limited to 65535, longer slabs take several launches
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
         const size_t nr = std::min<size_t>(65535, row_count - r0);
-        HIP_TRY(hipModuleLaunchKernel(m->rowstream6, (unsigned)cpr, (unsigned)nr, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params,
-                                      nullptr));
+        HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
+                                      (unsigned)(aos6 ? P : P * kOpWidth[op]), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
       }
     }
   } else if (row_uniform) {
@@ -364,8 +369,9 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
       return bail(INFLX_ERR_SYMBOL);
     }
   }
-  if (hipModuleGetFunction(&m->rowstream6, m->module, "inflx_sweep_rowstream6") != hipSuccess) {
-    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_sweep_rowstream6", artefact_path);
+  if (hipModuleGetFunction(&m->rowstream6, m->module, "inflx_sweep_rowstream6") != hipSuccess ||
+      hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 7u
+#define INFLX_KERNEL_ABI 8u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -46,7 +46,7 @@ struct InflxSweepArgs {
   // from a single line that fetch throttles the store stream to 5.1 TB/s, from 32 replicas it runs at 6.8.
   double* row_table;
   uint32_t table_replicas;
-  uint32_t reserved;
+  uint32_t stream_planes;  // inflx_sweep_rowstream_planes: K, the number of result planes per parameter row
   double accuracy;  // INFLX_OP_QDIF: threshold of ops::flag_quantum_diff
 };
 

@@ -326,6 +326,24 @@ __device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
 }
 static_assert(kThreads % 3 == 1, "the phase rule of sweep_rowstream6 needs kThreads == 1 (mod 3)");
 
+// The same store stream for results made of planes ([P][K][rows][N1]: the SoA layout, and every
+// single-value sweep with K = 1), N1 even: a plane row is N1/2 copies of the 16-byte unit (v, v).
+// grid = (pieces per plane row, rows, P*K).
+__device__ __forceinline__ void sweep_rowstream_planes(const InflxSweepArgs& a) {
+  const uint64_t units_row = a.N1 / 2;
+  const unsigned piece = blockIdx.x;
+  const uint64_t row = (uint64_t)a.stream_row0 + blockIdx.y;
+  const unsigned p = blockIdx.z / a.stream_planes;
+  const unsigned k = blockIdx.z - p * a.stream_planes;
+  const uint64_t slab_row = (uint64_t)p * a.row_count + row;
+  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + piece % a.table_replicas) * 8;
+  double v = t[k];
+  asm volatile("" : "+s"(v));
+  const uint64_t u = (uint64_t)piece * kThreads + threadIdx.x;
+  double* dst = a.out + (((uint64_t)p * a.stream_planes + k) * a.row_count + row) * a.N1;
+  if (u < units_row) __builtin_nontemporal_store(inflx_d2{v, v}, reinterpret_cast<inflx_d2*>(dst + 2 * u));
+}
+
 template <int OP>
 __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
   constexpr int K = OpWidth<OP>::K;
@@ -409,6 +427,9 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   }
 
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream_planes(const InflxSweepArgs a) {
+  sweep_rowstream_planes(a);
+}
 
 INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)
 INFLX_DEFINE_KERNELS(consistency, INFLX_OP_CONSISTENCY)
