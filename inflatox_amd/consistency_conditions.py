@@ -46,6 +46,25 @@ class InflationCondition:
         return np.array([[r[1], r[2]], [r[2], r[3]]])
 
 
+    # -- array helpers (reference :67-101,119-156); off the sweep path, served by the raw-values sweep ----
+    def _raw_planes(self, args, x0_start, x0_stop, x1_start, x1_stop, N):
+        n0, n1 = (int(v) for v in (N if N is not None else (8000, 8000)))
+        ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        return self.dylib.sweep_host(_native.OP_RAW, args, ss, n0, n1, layout=_native.LAYOUT_SOA)
+
+    def calc_V_array(self, args, start, stop, N=None) -> np.ndarray:
+        """Potential on the grid ``start[i] + k*(stop[i]-start[i])/N[i]`` (end point excluded), shape ``N``
+        (reference consistency_conditions.py:67-101, hesse_bindings.rs:68-85)."""
+        return self._raw_planes(args, start[0], stop[0], start[1], stop[1], N)[0]
+
+    def calc_H_array(self, args, x0_start, x0_stop, x1_start, x1_stop, N=None) -> np.ndarray:
+        """Projected Hesse matrix on the grid, shape (2, 2, N0, N1) as the reference documents
+        (consistency_conditions.py:119-156; its implementation passes the wrong arguments to the native
+        helper and cannot run, so the documented contract is what is implemented).  v01 is filled from v10."""
+        raw = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N)
+        return np.stack([np.stack([raw[1], raw[2]]), np.stack([raw[2], raw[3]])])
+
+
 class GeneralisedAL(InflationCondition):
     """Generalised Anguelova-Lazaroiu consistency condition and the quantities derived from it
     (reference consistency_conditions.py:199-715)."""

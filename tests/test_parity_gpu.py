@@ -263,3 +263,22 @@ def test_flag_quantum_dif(name, gpu_lib):
         # a gradient component within a few ulps of the threshold may flip; nothing else may
         assert (got != want).mean() <= 0.002, (name, accuracy, int((got != want).sum()))
     assert got.any() or not want.any()
+
+
+def test_array_helpers(gpu_lib):
+    """calc_V_array / calc_H_array (reference consistency_conditions.py:67-156) vs the oracle's raw values."""
+    from inflatox_amd import workloads
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    spec, art = workloads.artifact_for("doc")
+    al = GeneralisedAL(art)
+    om, _ = oracle_model("doc")
+    n0, n1 = 40, 26
+    raw = om.grid_sweep(OP.RAW, spec.args, (0.5, 2.5, 0.0, 3.0), n0, n1)
+    V = al.calc_V_array(spec.args, [0.5, 0.0], [2.5, 3.0], [n0, n1])
+    assert V.shape == (n0, n1)
+    compare(V, raw[..., 0], 1e-10, "calc_V_array")
+    H = al.calc_H_array(spec.args, 0.5, 2.5, 0.0, 3.0, [n0, n1])
+    assert H.shape == (2, 2, n0, n1)
+    for (a, b), k in (((0, 0), 1), ((1, 0), 2), ((0, 1), 2), ((1, 1), 3)):
+        compare(H[a, b], raw[..., k], 1e-9, f"calc_H_array[{a}{b}]")
