@@ -561,7 +561,8 @@ int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n
 int inflx_flag_quantum_dif(inflx_model* m, const double* p, size_t n_p, uint8_t* out, const double* ss, size_t N0, size_t N1,
                            int progress, double accuracy) {
   if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
-  if (progress) say("Calculating zeros of the potential gradient on HIP device %d.", m ? m->device : -1);
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (progress) say("Calculating zeros of the potential gradient on HIP device %d.", m->device);
   return sweep_host_impl(m, INFLX_OP_QDIF, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, accuracy);
 }
 

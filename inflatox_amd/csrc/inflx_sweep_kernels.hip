@@ -3,7 +3,7 @@
 // Compiled once per model by inflatox_amd.Compiler:
 //   hipcc --offload-arch=gfx950 --genco -O3 -DINFLX_MODEL_HEADER="<generated>.h" this_file -o model.hsaco
 // The generated header provides the model as four straight-line device functions
-// (inflx_stage_uniform / _row / _col / _point, see inflatox_amd/compiler.py) that are inlined
+// (inflx_stage_uniform / _row / _col / _point, see inflatox_amd/staging.py) that are inlined
 // here -- the counterpart of the reference calling V, v11, v10, v00, grad_norm_squared through
 // five dlsym'd pointers per grid point (src/anguelova.rs:110,119; src/hesse_bindings.rs:213-231).
 //
@@ -18,10 +18,14 @@
 //    For the 6-value AoS result a wavefront transposes its 64x6 block through a private 3 KiB LDS
 //    buffer so that every global store instruction writes 1 KiB of contiguous memory (16 B/lane).
 //
-//  * row kernels (inflx_sweep_rows_*): used when no model value depends on x[1] (e.g. the
-//    hyperbolic benchmark model): the per-point operation is then a function of the row only, is
-//    evaluated once per grid row, and the kernel degenerates into a pure 48 B/point store stream
-//    (three 16-B patterns rotating over the lanes), which is what the HBM roofline prices.
+//  * row-broadcast path, used when no model value depends on x[1] (e.g. the hyperbolic benchmark model):
+//    the per-point operation is then a function of the grid row only.  inflx_sweep_rowvals_* evaluates
+//    it once per row into a small table, inflx_sweep_rowstream6 / _planes broadcast it along the row:
+//    a pure store stream, ONE 16-byte store per thread and 4 KiB per workgroup, which is what the
+//    HBM roofline prices (7.0-7.1 TB/s measured).  inflx_sweep_rows_* is the fallback for result
+//    shapes the stream kernels do not cover (odd N1 planes, the 5-value AoS diagnostic).
+//
+//  * inflx_sweep_traj_*: explicit point lists (src/anguelova.rs:633-977), one thread per point.
 //
 // Numerics: IEEE-strict FP64 (no fast-math, denormals kept, correctly rounded div/sqrt).
 #include <hip/hip_runtime.h>
