@@ -100,8 +100,16 @@ struct inflx_model {
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
   hipFunction_t rowstream_planes = nullptr;
-  double* d_row_table = nullptr;  // [P][rows][8] per-row results of the row-broadcast path
-  size_t d_row_table_cap = 0;
+  // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
+  // evaluation of sweep n runs on `side` and overlaps the store stream of sweep n-1 on the caller's
+  // stream (it needs ~25 us of latency but hardly any bandwidth); events order table reuse.
+  double* d_row_table[2] = {nullptr, nullptr};
+  size_t d_row_table_cap[2] = {0, 0};
+  hipStream_t side = nullptr;
+  hipEvent_t table_ready[2] = {nullptr, nullptr};  // rowvals finished writing buffer b
+  hipEvent_t table_free[2] = {nullptr, nullptr};   // the store stream that last read buffer b finished
+  bool table_used[2] = {false, false};
+  unsigned table_turn = 0;
   InflxKernelInfo info = {};
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
@@ -147,6 +155,9 @@ int ensure_params(inflx_model* m, const double* p, size_t count, hipStream_t s) 
   if (m->params_on_device.size() == count && m->params_stream == s &&
       memcmp(m->params_on_device.data(), p, count * sizeof(double)) == 0)
     return INFLX_OK;
+  // the kernels that read d_params run on the stream of the upload before them; when that stream
+  // changes, let the old one finish before its parameters are overwritten
+  if (m->params_stream && m->params_stream != s) HIP_TRY(hipStreamSynchronize(m->params_stream));
   HIP_TRY(hipMemcpyAsync(m->d_params, p, count * sizeof(double), hipMemcpyHostToDevice, s));
   m->params_on_device.assign(p, p + count);
   m->params_stream = s;
@@ -168,14 +179,24 @@ int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p
 }
 
 // Enqueue one sweep launch on `s`; `d_params` points at P parameter rows in device memory.
-int ensure_row_table(inflx_model* m, size_t doubles) {
-  if (doubles <= m->d_row_table_cap) return INFLX_OK;
-  if (m->d_row_table) HIP_TRY(hipFree(m->d_row_table));
-  m->d_row_table = nullptr;
-  m->d_row_table_cap = 0;
-  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_row_table), doubles * sizeof(double)));
-  m->d_row_table_cap = doubles;
+int ensure_row_table(inflx_model* m, int b, size_t doubles) {
+  if (doubles <= m->d_row_table_cap[b]) return INFLX_OK;
+  // a larger table is needed: nothing may still be using the old one
+  HIP_TRY(hipDeviceSynchronize());
+  if (m->d_row_table[b]) HIP_TRY(hipFree(m->d_row_table[b]));
+  m->d_row_table[b] = nullptr;
+  m->d_row_table_cap[b] = 0;
+  HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_row_table[b]), doubles * sizeof(double)));
+  m->d_row_table_cap[b] = doubles;
   return INFLX_OK;
+}
+
+// does this sweep take the two-launch row-broadcast path (per-row evaluation + store stream)?
+bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
+  if ((m->info.out_mask & 2u) != 0 || op == INFLX_OP_QDIF) return false;
+  const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
+  const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0 && P * kOpWidth[op] <= 65535;
+  return aos6 || planes;
 }
 
 // `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
@@ -204,8 +225,7 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
   if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
   const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
-  const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0 && P * kOpWidth[op] <= 65535;
-  if (row_uniform && (aos6 || planes)) {
+  if (takes_row_stream(m, op, layout, P, N1)) {
     // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
     // store per thread, 4 KiB per workgroup); `what` selects both (0), or one of them for timing
     const size_t units_row = aos6 ? 3 * N1 : N1 / 2;
@@ -214,14 +234,22 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     // replicas of every row's table entry (see inflx_kernel_abi.h); fewer when the table would get large
     size_t replicas = 32;  // always a power of two (the evaluation kernel indexes with shifts)
     while (replicas > 1 && (P * row_count * replicas * 64 > (size_t(1) << 30) || replicas > cpr)) replicas /= 2;
-    int rc = ensure_row_table(m, P * row_count * replicas * 8);
+    // `what` == 2 re-runs only the store stream from the most recently filled table
+    const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
+    int rc = ensure_row_table(m, b, P * row_count * replicas * 8);
     if (rc) return rc;
-    a.row_table = m->d_row_table;
+    a.row_table = m->d_row_table[b];
     a.table_replicas = (uint32_t)replicas;
     a.stream_planes = (uint32_t)kOpWidth[op];
-    if (what != 2)
-      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)P, 1, 64, 1, 1, 0, s, params, nullptr));
+    if (what != 2) {
+      // per-row evaluation on the side stream, as soon as the previous reader of this table is done
+      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)P, 1, 64, 1, 1, 0, m->side, params, nullptr));
+      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+      m->table_turn++;
+    }
     if (what != 1) {
+      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
       // grid.y is limited to 65535, longer slabs take several launches
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
@@ -229,6 +257,8 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
         HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
                                       (unsigned)(aos6 ? P : P * kOpWidth[op]), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
       }
+      HIP_TRY(hipEventRecord(m->table_free[b], s));
+      m->table_used[b] = true;
     }
   } else if (row_uniform) {
     const size_t rpb = m->info.rows_per_block;
@@ -375,12 +405,15 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
     return bail(INFLX_ERR_SYMBOL);
   }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     fail(INFLX_ERR_DEVICE, "could not create HIP streams");
     return bail(INFLX_ERR_DEVICE);
   }
   for (int k = 0; k < 2; ++k) {
     if (hipEventCreateWithFlags(&m->chunk_done[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->table_ready[k], hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&m->table_free[k], hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&m->copy_done[k], hipEventDisableTiming) != hipSuccess) {
       fail(INFLX_ERR_DEVICE, "could not create HIP events");
       return bail(INFLX_ERR_DEVICE);
@@ -398,17 +431,21 @@ void inflx_close(inflx_model* m) {
   if (!m) return;
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
+  if (m->side) (void)hipStreamSynchronize(m->side);
   if (m->copy_stream) (void)hipStreamSynchronize(m->copy_stream);
   for (int k = 0; k < 2; ++k) {
     if (m->d_chunk[k]) (void)hipFree(m->d_chunk[k]);
     if (m->chunk_done[k]) (void)hipEventDestroy(m->chunk_done[k]);
     if (m->copy_done[k]) (void)hipEventDestroy(m->copy_done[k]);
+    if (m->table_ready[k]) (void)hipEventDestroy(m->table_ready[k]);
+    if (m->table_free[k]) (void)hipEventDestroy(m->table_free[k]);
+    if (m->d_row_table[k]) (void)hipFree(m->d_row_table[k]);
   }
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->d_params) (void)hipFree(m->d_params);
-  if (m->d_row_table) (void)hipFree(m->d_row_table);
   if (m->stream) (void)hipStreamDestroy(m->stream);
+  if (m->side) (void)hipStreamDestroy(m->side);
   if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
   if (m->module) (void)hipModuleUnload(m->module);
   delete m;
@@ -431,6 +468,7 @@ int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t*
 int inflx_synchronize(inflx_model* m) {
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->side));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return INFLX_OK;
 }
@@ -447,7 +485,9 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   if (d_out_bytes < need) return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, need);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  if ((rc = ensure_params(m, p, P * n_p, s))) return rc;
+  // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
+  // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
+  if ((rc = ensure_params(m, p, P * n_p, takes_row_stream(m, op, layout, P, N1) ? m->side : s))) return rc;
   return launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
 }
 
@@ -488,7 +528,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
   if (row_count == 0 || N1 == 0) return INFLX_OK;
   HIP_TRY(hipSetDevice(m->device));
-  if ((rc = ensure_params(m, p, P * n_p, m->stream))) return rc;
+  if ((rc = ensure_params(m, p, P * n_p, takes_row_stream(m, op, layout, 1, N1) ? m->side : m->stream))) return rc;
 
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
