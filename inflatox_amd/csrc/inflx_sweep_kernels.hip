@@ -54,6 +54,10 @@
 #ifndef INFLX_MIN_WAVES
 #define INFLX_MIN_WAVES 2
 #endif
+// tile kernels: unroll factor of the loop over the tile's rows (1 = none)
+#ifndef INFLX_ROW_UNROLL
+#define INFLX_ROW_UNROLL 1
+#endif
 // tile kernels: keep the parameter-only (U) values in LDS instead of 2 VGPRs each
 #ifndef INFLX_U_IN_LDS
 #define INFLX_U_IN_LDS (INFLX_NU > 8)
@@ -196,6 +200,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const uint64_t cols_left = wave_col0 < a.N1 ? a.N1 - wave_col0 : 0;
   const unsigned wave_units = cols_left >= kWave ? 3u * kWave : 3u * (unsigned)cols_left;
 
+#pragma unroll INFLX_ROW_UNROLL
   for (int r = 0; r < nrows; ++r) {
     const uint64_t row = row0 + r;
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);

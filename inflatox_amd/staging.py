@@ -141,8 +141,7 @@ class HIPInflatoxPrinter(C99CodePrinter):
         prec = precedence(expr)
         sign, num, den, paren = split_product(expr)
         if self.stager is not None:
-            num = self.stager.group(num, "*")
-            den = self.stager.group(den, "*")
+            num, den = self.stager.group_quotient(num, den)
         if len(num) == 1 and sign == "-":
             num_s = [self._operand(num[0], 0.5 * (PRECEDENCE["Pow"] + PRECEDENCE["Mul"]))]
         else:
@@ -204,18 +203,19 @@ class _Group(sympy.AtomicExpr):
     is_commutative = True
     is_number = False
 
-    def __new__(cls, op, items):
+    def __new__(cls, op, items, den=()):
         obj = sympy.AtomicExpr.__new__(cls)
         obj.op = op
         obj.items = tuple(items)
+        obj.den = tuple(den)  # op "/": items / den
         return obj
 
     def _hashable_content(self):
-        return (self.op, self.items)
+        return (self.op, self.items, self.den)
 
     @property
     def free_symbols(self):
-        return set().union(*[i.free_symbols for i in self.items])
+        return set().union(*[i.free_symbols for i in self.items + self.den])
 
 
 class Stager:
@@ -295,7 +295,7 @@ class Stager:
             return C
         if isinstance(e, _Group):
             m = 0
-            for i in e.items:
+            for i in e.items + e.den:
                 m |= self.mask(i)
             return m
         if e.is_Atom:
@@ -355,6 +355,60 @@ class Stager:
                 merged.append(it)
         return merged
 
+    def group_quotient(self, num, den):
+        """Fast mode only (``regroup``): inside a product printed in stage ctx, the numerator and
+        denominator factors of each lower class become ONE stage variable num/den, so that the division
+        is done once per row/column instead of once per point.  Not exact: (a*c)/b becomes c*(a/b)."""
+        if not self.staged or not self.regroup:
+            return num, den
+        ctx = self._ctx
+
+        def movable(it):
+            # numeric constants travel with the parameter-only class (a constant denominator such as
+            # pi^3 would otherwise keep a per-point division alive)
+            return self.mask(it) != ctx and (it.free_symbols or (ctx != U and not it.is_Rational))
+
+        classes = {}
+        for it in num:
+            if movable(it):
+                classes.setdefault(self.mask(it), ([], []))[0].append(it)
+        for it in den:
+            if movable(it):
+                classes.setdefault(self.mask(it), ([], []))[1].append(it)
+        # parameter-only factors ride along with the row (else column) factors of the same product:
+        # one multiplication less per point and one exported value less
+        fold = {}
+        if ctx == P and U in classes and (R in classes or C in classes):
+            target = R if R in classes else C
+            classes[target][0].extend(classes[U][0])
+            classes[target][1].extend(classes[U][1])
+            del classes[U]
+            fold[U] = target
+        merged = {m: _Group("/", n, d) for m, (n, d) in classes.items() if (len(n) + len(d) >= 2 or d) and any(i.free_symbols for i in n + d)}
+        if not merged:
+            return num, den
+        for src, dst in fold.items():
+            if dst in merged:
+                merged[src] = merged[dst]
+        new_num, done = [], set()
+        for it in num:
+            m = self.mask(it)
+            if m in merged and movable(it):
+                m = fold.get(m, m)
+                if m not in done:
+                    done.add(m)
+                    new_num.append(merged[m])
+            else:
+                new_num.append(it)
+        for m, g in merged.items():
+            if fold.get(m, m) not in done:
+                done.add(fold.get(m, m))
+                new_num.append(g)  # class present in the denominator only: contributes 1/den
+        new_den = [it for it in den if not (self.mask(it) in merged and movable(it))]
+        if new_num and new_num[0] is sympy.S.One and len(new_num) > 1:
+            new_num = new_num[1:]
+        return new_num, new_den
+
     # -- stage variables ---------------------------------------------------------------------------
     def _reference(self, name):
         self.used_by[name].add(self._ctx)
@@ -368,6 +422,10 @@ class Stager:
             if isinstance(e, _Group):
                 if e.op == "*":
                     text = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items)
+                elif e.op == "/":
+                    top = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items) if e.items else "1.0"
+                    bottom = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.den)
+                    text = top if not e.den else (f"{top}/{bottom}" if len(e.den) == 1 else f"{top}/({bottom})")
                 else:
                     text = self._sum_text(e.items)
             else:
