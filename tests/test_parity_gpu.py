@@ -282,3 +282,30 @@ def test_array_helpers(gpu_lib):
     assert H.shape == (2, 2, n0, n1)
     for (a, b), k in (((0, 0), 1), ((1, 0), 2), ((0, 1), 2), ((1, 1), 3)):
         compare(H[a, b], raw[..., k], 1e-9, f"calc_H_array[{a}{b}]")
+
+
+@pytest.mark.parametrize("name,loader", [("angular", "npy2"), ("egno", "npy2"), ("d5", "dat")])
+def test_reference_trajectory_fixtures(name, loader, gpu_lib):
+    """The on-trajectory calls of the reference's own tests (tests/test_angular.py:75-78,
+    tests/test_egno.py:96-99, tests/test_d5.py:165-167) on the trajectory files those tests hold."""
+    import os
+
+    from conftest import GOLDEN_DIR
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    d = os.path.join(GOLDEN_DIR, "trajectories")
+    if name == "angular":
+        traj = np.column_stack((np.load(os.path.join(d, "angular_phix.npy")), np.load(os.path.join(d, "angular_phiy.npy"))))
+    elif name == "egno":
+        traj = np.column_stack((np.load(os.path.join(d, "egno_r.npy")), np.load(os.path.join(d, "egno_theta.npy"))))
+    else:
+        traj = np.loadtxt(os.path.join(d, "d5_trajectory.dat"))
+    spec, art, lib = devlib(name, gpu_lib)
+    om, _ = oracle_model(name)
+    al = GeneralisedAL(art)
+    six = al.complete_analysis_ot(spec.args, traj, progress=False)
+    assert len(six) == 6 and all(a.shape == (traj.shape[0], 1) for a in six)  # np.split(out, 6, 1), like the reference
+    got = np.concatenate(six, axis=1)
+    want = om.trajectory_sweep(OP.COMPLETE, spec.args, traj)
+    raw = om.trajectory_sweep(OP.RAW, spec.args, traj)
+    judge(name, spec.args, traj, (traj.shape[0],), raw, got, want, tol.epilogue, f"{name}/reference trajectory")
