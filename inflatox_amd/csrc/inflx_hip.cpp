@@ -318,7 +318,8 @@ int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out,
   if (rc) return rc;
   if (progress) {
     const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    say("Calculation finished. Took %.3f s.", sec);
+    say("Calculation finished. Took %.3f s (%.3g grid points/s including the copy to host memory).", sec,
+        (double)N0 * (double)N1 / std::max(sec, 1e-9));
   }
   return INFLX_OK;
 }

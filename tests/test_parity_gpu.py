@@ -309,3 +309,69 @@ def test_reference_trajectory_fixtures(name, loader, gpu_lib):
     want = om.trajectory_sweep(OP.COMPLETE, spec.args, traj)
     raw = om.trajectory_sweep(OP.RAW, spec.args, traj)
     judge(name, spec.args, traj, (traj.shape[0],), raw, got, want, tol.epilogue, f"{name}/reference trajectory")
+
+
+def test_parameter_axis_at_full_grid_size(gpu_lib):
+    """BASELINE config 5 in miniature: the 8192 x 8192 hyperbolic sweep for P = 4 parameter rows in ONE
+    launch (12.9 GB device-resident).  Every column equals column 0, and column 0 of every parameter
+    row equals the oracle's 8192 x 1 sweep with that row's parameters."""
+    import torch
+
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    n, P = 8192, 4
+    rows = np.stack([spec.args * np.array([1.0, 1.0, 1.0 + 0.25 * k]) for k in range(P)])  # L varies, as in configs[4]
+    out = torch.empty((P, n, n, 6), dtype=torch.float64, device="cuda:0")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    om, _ = oracle_model("hyperbolic")
+    for k in range(P):
+        col0 = out[k, :, :1, :]
+        same = (out[k] == col0) | (torch.isnan(out[k]) & torch.isnan(col0))
+        assert bool(same.all()), k
+        want = om.grid_sweep(OP.COMPLETE, rows[k], spec.extent, n, 1)[:, 0, :]
+        compare(col0[:, 0, :].cpu().numpy(), want, 1e-10, f"hyperbolic/8192 P-row {k}")
+    del out
+
+
+def test_d5_parameter_axis_sampled(gpu_lib):
+    """BASELINE config 3 shape (D5, parameter axis over a1): 2048 x 2048 x P = 6 in one launch, sampled
+    against the oracle."""
+    import torch
+
+    spec, art, lib = devlib("d5", gpu_lib)
+    n, P = 2048, 6
+    rows = np.tile(spec.args, (P, 1))
+    rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)  # a1, SURVEY section 8(d)
+    out = torch.empty((P, n, n, 6), dtype=torch.float64, device="cuda:0")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(5)
+    om, _ = oracle_model("d5")
+    x0a, x0b, x1a, x1b = spec.extent
+    for k in range(P):
+        ii, jj = rng.integers(0, n, 1500), rng.integers(0, n, 1500)
+        pts = np.column_stack([ii * ((x0b - x0a) / n) + x0a, jj * ((x1b - x1a) / n) + x1a])
+        want = om.trajectory_sweep(OP.COMPLETE, rows[k], pts)
+        raw = om.trajectory_sweep(OP.RAW, rows[k], pts)
+        got = out[k][torch.as_tensor(ii, device="cuda:0"), torch.as_tensor(jj, device="cuda:0")].cpu().numpy()
+        judge("d5", rows[k], pts, (1500,), raw, got, want, tol.epilogue, f"d5/P-row {k}")
+
+
+def test_sharded_sweep_with_hip_compute(gpu_lib):
+    """inflatox_amd.distributed on one GPU (world = 1): the plan owns everything, the block equals sweep_host."""
+    from inflatox_amd.distributed import HipCompute, ShardedSweep, plan_shard
+
+    spec, art, lib = devlib("doc", gpu_lib)
+    n0, n1 = 96, 130
+    rows = np.stack([spec.args, spec.args * 1.5])
+    plan, block = ShardedSweep(HipCompute(lib, spec.extent, n0, n1), 0, 1).run(rows, n0)
+    assert plan == plan_shard(2, n0, 1, 0) and tuple(block.shape) == (2, n0, n1, 6)
+    import torch
+
+    torch.cuda.synchronize()
+    want = lib.sweep_host(gpu_lib.OP_COMPLETE, rows, spec.extent, n0, n1)
+    assert np.array_equal(block.cpu().numpy(), want, equal_nan=True)
+    # a rank that owns rows [40, 70) only
+    part = HipCompute(lib, spec.extent, n0, n1)(rows, 40, 30)
+    torch.cuda.synchronize()
+    assert np.array_equal(part.cpu().numpy(), want[:, 40:70], equal_nan=True)
