@@ -178,7 +178,6 @@ int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p
   return INFLX_OK;
 }
 
-// Enqueue one sweep launch on `s`; `d_params` points at P parameter rows in device memory.
 int ensure_row_table(inflx_model* m, int b, size_t doubles) {
   if (doubles <= m->d_row_table_cap[b]) return INFLX_OK;
   // a larger table is needed: nothing may still be using the old one
@@ -199,6 +198,7 @@ bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   return aos6 || planes;
 }
 
+// Enqueue one sweep on `s`; `d_params` points at P parameter rows in device memory.
 // `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
 // 2 = only the store stream (used to time the dominant kernel on its own).
 int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
