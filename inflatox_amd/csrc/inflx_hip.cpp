@@ -231,34 +231,48 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     const size_t units_row = aos6 ? 3 * N1 : N1 / 2;
     const size_t cpr = (units_row + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
     if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
-    // replicas of every row's table entry (see inflx_kernel_abi.h); fewer when the table would get large
-    size_t replicas = 32;  // always a power of two (the evaluation kernel indexes with shifts)
-    while (replicas > 1 && (P * row_count * replicas * 64 > (size_t(1) << 30) || replicas > cpr)) replicas /= 2;
-    // `what` == 2 re-runs only the store stream from the most recently filled table
-    const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
-    int rc = ensure_row_table(m, b, P * row_count * replicas * 8);
-    if (rc) return rc;
-    a.row_table = m->d_row_table[b];
-    a.table_replicas = (uint32_t)replicas;
-    a.stream_planes = (uint32_t)kOpWidth[op];
-    if (what != 2) {
-      // per-row evaluation on the side stream, as soon as the previous reader of this table is done
-      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
-      HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)P, 1, 64, 1, 1, 0, m->side, params, nullptr));
-      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
-      m->table_turn++;
-    }
-    if (what != 1) {
-      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
-      // grid.y is limited to 65535, longer slabs take several launches
-      for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
-        a.stream_row0 = (uint32_t)r0;
-        const size_t nr = std::min<size_t>(65535, row_count - r0);
-        HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
-                                      (unsigned)(aos6 ? P : P * kOpWidth[op]), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+    // replicas of every row's table entry (see inflx_kernel_abi.h); a power of two (the evaluation
+    // kernel indexes with shifts), fewer for short rows
+    size_t replicas = 32;
+    while (replicas > 1 && replicas > cpr) replicas /= 2;
+    // The table has to stay in the 256 MiB Infinity Cache between its evaluation and its use (a table
+    // fetch from HBM throttles the store stream from 6.6 to 5.0 TB/s, measured at P = 16): parameter
+    // rows are processed in batches whose table is at most 64 MiB, each batch = evaluation + stream,
+    // and the double-buffered side stream overlaps the evaluation of batch k+1 with the stream of batch k.
+    const size_t line_bytes = row_count * replicas * 64;
+    const size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(line_bytes, 1)));
+    const size_t K = kOpWidth[op];
+    for (size_t p0 = 0; p0 < P; p0 += batch) {
+      const size_t pb = std::min(batch, P - p0);
+      // `what` == 2 (timing only) re-runs the store streams from whatever the tables hold
+      const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
+      int rc = ensure_row_table(m, b, pb * row_count * replicas * 8);
+      if (rc) return rc;
+      a.params = d_params + p0 * m->n_par;
+      a.out = d_out + p0 * row_count * N1 * K;  // same offset for [P][rows][N1][K] and [P][K][rows][N1]
+      a.P = (uint32_t)pb;
+      a.row_table = m->d_row_table[b];
+      a.table_replicas = (uint32_t)replicas;
+      a.stream_planes = (uint32_t)K;
+      if (what != 2) {
+        // per-row evaluation on the side stream, as soon as the previous reader of this table is done
+        if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+        HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0, m->side, params, nullptr));
+        HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+        m->table_turn++;
       }
-      HIP_TRY(hipEventRecord(m->table_free[b], s));
-      m->table_used[b] = true;
+      if (what != 1) {
+        HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+        // grid.y is limited to 65535, longer slabs take several launches
+        for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
+          a.stream_row0 = (uint32_t)r0;
+          const size_t nr = std::min<size_t>(65535, row_count - r0);
+          HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
+                                        (unsigned)(aos6 ? pb : pb * K), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+        }
+        HIP_TRY(hipEventRecord(m->table_free[b], s));
+        m->table_used[b] = true;
+      }
     }
   } else if (row_uniform) {
     const size_t rpb = m->info.rows_per_block;
