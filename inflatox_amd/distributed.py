@@ -106,16 +106,24 @@ class HipCompute:
     """The product's local sweep: one ``inflx_sweep_device`` launch into a torch CUDA tensor."""
 
     def __init__(self, devlib: _native.InflatoxDevLib, extent, N0: int, N1: int, op: int = _native.OP_COMPLETE):
+        import torch
+
         self.lib = devlib
         self.extent = extent
         self.N0, self.N1, self.op = N0, N1, op
+        # a torch-owned stream for the sweep: torch's default stream has the NULL handle, which the C ABI
+        # reads as "use the model's own stream", and that one is not ordered with torch's work
+        self.stream = torch.cuda.Stream(device=f"cuda:{devlib.device}")
 
     def __call__(self, p_rows, row_begin, row_count):
         import torch
 
         k = _native.OP_WIDTH[self.op]
-        out = torch.empty((len(p_rows), row_count, self.N1, k), dtype=torch.float64, device=f"cuda:{self.lib.device}")
+        device = torch.device(f"cuda:{self.lib.device}")
+        out = torch.empty((len(p_rows), row_count, self.N1, k), dtype=torch.float64, device=device)
         if out.numel():
+            consumer = torch.cuda.current_stream(device)
+            self.stream.wait_stream(consumer)  # `out` was allocated on the consumer's stream
             self.lib.sweep_device(
                 self.op,
                 p_rows,
@@ -126,6 +134,8 @@ class HipCompute:
                 self.N1,
                 row_begin=row_begin,
                 row_count=row_count,
-                stream=torch.cuda.current_stream(out.device).cuda_stream,
+                stream=self.stream.cuda_stream,
             )
+            consumer.wait_stream(self.stream)  # whatever torch does next with `out` (e.g. the all-gather) is ordered after the sweep
+            out.record_stream(self.stream)
         return out
