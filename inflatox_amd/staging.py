@@ -161,7 +161,7 @@ class HIPInflatoxPrinter(C99CodePrinter):
     def _print_Add(self, expr, order=None):
         terms = self._as_ordered_terms(expr, order=order)
         if self.stager is not None:
-            terms = self.stager.group(terms, "+")
+            terms = self.stager.group_terms(terms)
         prec = precedence(expr)
         parts = []
         for term in terms:
@@ -198,7 +198,8 @@ class HIPInflatoxPrinter(C99CodePrinter):
 
 
 class _Group(sympy.AtomicExpr):
-    """Placeholder standing for 'the operands of one class inside an n-ary product/sum'."""
+    """Placeholder (fast mode) for 'the operands of one axis class inside an n-ary product or sum':
+    op "/" = product of ``items`` divided by the product of ``den``; op "+" = sum of ``items``."""
 
     is_commutative = True
     is_number = False
@@ -333,9 +334,10 @@ class Stager:
             return self._variable(e, m)
         return self.printer.print_node(e)
 
-    def group(self, items, op):
-        """Within an n-ary product/sum printed in stage ctx: merge the operands of each lower class
-        (>= 2 of them) into one placeholder, keeping the printed order otherwise."""
+    def group_terms(self, items):
+        """Fast mode only (``regroup``): within a sum printed in stage ctx, the terms of each lower class
+        (>= 2 of them) are added first and become one stage variable; printed order is kept otherwise."""
+        op = "+"
         if not self.staged or len(items) < 2 or not self.regroup:
             return items
         ctx = self._ctx
@@ -420,9 +422,7 @@ class Stager:
             saved = self._ctx
             self._ctx = m
             if isinstance(e, _Group):
-                if e.op == "*":
-                    text = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items)
-                elif e.op == "/":
+                if e.op == "/":
                     top = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items) if e.items else "1.0"
                     bottom = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.den)
                     text = top if not e.den else (f"{top}/{bottom}" if len(e.den) == 1 else f"{top}/({bottom})")
