@@ -142,6 +142,8 @@ class HIPInflatoxPrinter(C99CodePrinter):
         sign, num, den, paren = split_product(expr)
         if self.stager is not None:
             num, den = self.stager.group_quotient(num, den)
+            num = self.stager.hoist_prefix(num, "*")
+            den = self.stager.hoist_prefix(den, "*")
         if len(num) == 1 and sign == "-":
             num_s = [self._operand(num[0], 0.5 * (PRECEDENCE["Pow"] + PRECEDENCE["Mul"]))]
         else:
@@ -161,7 +163,7 @@ class HIPInflatoxPrinter(C99CodePrinter):
     def _print_Add(self, expr, order=None):
         terms = self._as_ordered_terms(expr, order=order)
         if self.stager is not None:
-            terms = self.stager.group_terms(terms)
+            terms = self.stager.hoist_prefix(self.stager.group_terms(terms), "+")
         prec = precedence(expr)
         parts = []
         for term in terms:
@@ -357,6 +359,30 @@ class Stager:
                 merged.append(it)
         return merged
 
+    def hoist_prefix(self, items, op):
+        """EXACT: C evaluates ``a*b*c*d`` as ``((a*b)*c)*d`` and ``a+b+c`` as ``(a+b)+c``.  If the first
+        k >= 2 operands of a product (or sum) printed in stage ctx together depend on fewer axes than
+        ctx, their partial product (sum) is the very value the reference computes on the way, so it can
+        be evaluated once in the lower stage without changing a bit.  (A denominator ``/(d1*d2*d3)`` is a
+        product of its own, so a row-only denominator becomes one row-stage value.)"""
+        if not self.staged or len(items) < 2:
+            return items
+        ctx = self._ctx
+        cumulative, k, best = 0, 0, None
+        for it in items:
+            cumulative |= self.mask(it)
+            if cumulative == ctx:
+                break
+            k += 1
+            if k >= 2 and any(i.free_symbols for i in items[:k]):
+                best = (k, cumulative)
+        if best is None:
+            return items
+        k, m = best
+        if k == len(items) and m == ctx:
+            return items
+        return [_Group(op + "prefix", items[:k])] + list(items[k:])
+
     def group_quotient(self, num, den):
         """Fast mode only (``regroup``): inside a product printed in stage ctx, the numerator and
         denominator factors of each lower class become ONE stage variable num/den, so that the division
@@ -422,7 +448,11 @@ class Stager:
             saved = self._ctx
             self._ctx = m
             if isinstance(e, _Group):
-                if e.op == "/":
+                if e.op == "*prefix":
+                    text = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items)
+                elif e.op == "+prefix":
+                    text = self._sum_text(e.items)
+                elif e.op == "/":
                     top = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items) if e.items else "1.0"
                     bottom = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.den)
                     text = top if not e.den else (f"{top}/{bottom}" if len(e.den) == 1 else f"{top}/({bottom})")
