@@ -442,8 +442,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
   }
   for (int k = 0; k < 2; ++k) {
     if (hipEventCreateWithFlags(&m->chunk_done[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->table_ready[k], hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&m->table_free[k], hipEventDisableTiming) != hipSuccess ||
+        // ordering-only events between two streams of this device: no system-scope fence needed (the
+        // kernels' own agent-scope release/acquire at their boundaries publishes the row table)
+        hipEventCreateWithFlags(&m->table_ready[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&m->table_free[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipEventCreateWithFlags(&m->copy_done[k], hipEventDisableTiming) != hipSuccess) {
       fail(INFLX_ERR_DEVICE, "could not create HIP events");
       return bail(INFLX_ERR_DEVICE);
