@@ -340,7 +340,17 @@ class Compiler:
         for d in deps:
             with open(d, "rb") as fh:
                 h.update(fh.read())
-        h.update(" ".join(self.hipcc_opts).encode())
+        opts = list(self.hipcc_opts)
+        # the tile kernels keep TILE_ROWS x n_row doubles of row-stage values in LDS: shrink the tile for
+        # models with very many row values so that it stays within ~64 KiB (two workgroups per CU)
+        n_row = max(1, (self.stage_info or {}).get("nr", 1))
+        if not any(o.startswith("-DINFLX_TILE_ROWS") for o in opts):
+            rows = 32
+            while rows > 4 and rows * n_row * 8 > 64 * 1024:
+                rows //= 2
+            if rows != 32:
+                opts.append(f"-DINFLX_TILE_ROWS={rows}")
+        h.update(" ".join(opts).encode())
         tag = h.hexdigest()[:20]
         cache = _cache_dir()
         cached = os.path.join(cache, f"{tag}.hsaco")
@@ -351,7 +361,7 @@ class Compiler:
             with open(header_path, "w") as fh:
                 fh.write(header_text)
             tmp_out = cached + f".{os.getpid()}.tmp"
-            cmd = [hipcc_path(), *self.hipcc_opts, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
+            cmd = [hipcc_path(), *opts, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
             proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
             log, code = proc.stdout, proc.returncode
             if code == 0:
