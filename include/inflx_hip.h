@@ -130,6 +130,28 @@ int inflx_sweep_device_timed(inflx_model* model, int op, const double* p, size_t
                              size_t row_count, int layout, void* stream, int repeats, int dominant_only,
                              float* ms_per_launch);
 
+/*
+ * Running summary of the six complete_analysis outputs over a sweep (no counterpart in the reference's
+ * native module; its users compute such statistics afterwards with numpy, e.g. np.nanmax in
+ * tests/test_doc.py:58).  NaN values are ignored, +-Inf count as values; min/max are +Inf/-Inf for a
+ * quantity that is NaN everywhere.
+ */
+typedef struct inflx_summary {
+  double min[6];     /* per quantity k: consistency, epsilon_V, epsilon_H, eta, delta, omega */
+  double max[6];
+  uint64_t count[6]; /* number of non-NaN values */
+} inflx_summary;
+
+/*
+ * complete_analysis sweep (AoS layout) with the summary reduced on the device inside the sweep kernels
+ * (wave-wide butterfly reduction + one set of f64 atomics per wavefront).  `d_out` may be NULL: the sweep
+ * then only evaluates and reduces and writes no result array.  Synchronous: returns when the summary is
+ * in `*summary`.
+ */
+int inflx_sweep_device_stats(inflx_model* model, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
+                             const double* start_stop, size_t N0, size_t N1, size_t row_begin, size_t row_count,
+                             void* stream, inflx_summary* summary);
+
 /* wait for everything enqueued on the model's own stream */
 int inflx_synchronize(inflx_model* model);
 

@@ -52,8 +52,18 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     ),
+    "inflx_sweep_device_stats": (
+        C.c_int,
+        [C.c_void_p, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_void_p, C.c_void_p],
+    ),
     "inflx_synchronize": (C.c_int, [C.c_void_p]),
 }
+
+
+class Summary(C.Structure):
+    """``inflx_summary``: NaN-ignoring min / max and the non-NaN count of the six outputs."""
+
+    _fields_ = [("min", C.c_double * 6), ("max", C.c_double * 6), ("count", C.c_uint64 * 6)]
 
 _lib = None
 
@@ -289,6 +299,21 @@ class InflatoxDevLib:
             )
         )
         return float(ms.value)
+
+    def sweep_stats(self, p, start_stop, N0, N1, row_begin=0, row_count=None, d_out_ptr: int = 0, d_out_bytes: int = 0, stream: int = 0) -> dict:
+        """complete_analysis sweep with the summary reduced on the device; with ``d_out_ptr == 0`` nothing
+        but the summary is produced.  Returns ``{"min": (P-agnostic) array(6), "max": array(6), "count": array(6)}``."""
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        row_count = N0 - row_begin if row_count is None else row_count
+        out = Summary()
+        _check(
+            self._lib.inflx_sweep_device_stats(
+                self._h, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, C.c_void_p(stream), C.byref(out)
+            )
+        )
+        return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))

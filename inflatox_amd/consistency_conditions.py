@@ -112,6 +112,14 @@ class GeneralisedAL(InflationCondition):
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
         return self.dylib.sweep_host(_native.OP_COMPLETE, np.atleast_2d(np.asarray(args, dtype=np.float64)), ss, N_x0, N_x1, layout=lay)
 
+    def complete_analysis_summary(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000) -> dict:
+        """Extension: NaN-ignoring minimum, maximum and non-NaN count of the six quantities over the sweep,
+        reduced on the GPU inside the sweep kernels -- what ``np.nanmin/np.nanmax`` over the six arrays of
+        :meth:`complete_analysis` would give (the reference's tests do exactly that, tests/test_doc.py:58),
+        without materialising or copying the arrays.  ``args`` may be (P, n_parameters)."""
+        ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        return self.dylib.sweep_stats(args, ss, N_x0, N_x1)
+
     # ---- single-quantity sweeps (reference :310-475) ---------------------------------------------
     def _single(self, fn, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads):
         out = np.zeros((N_x0, N_x1), dtype=float)

@@ -15,6 +15,7 @@
 #include <algorithm>
 #include <cerrno>
 #include <chrono>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -115,6 +116,8 @@ struct inflx_model {
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
   hipFunction_t rowstream_planes = nullptr;
+  hipFunction_t tile_stats = nullptr, tile_stats_nostore = nullptr, rowvals_stats = nullptr;
+  double* d_stats = nullptr;  // 18 x 8 bytes: min[6], max[6], count[6]
   // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
   // evaluation of sweep n runs on `side` and overlaps the store stream of sweep n-1 on the caller's
   // stream (it needs ~25 us of latency but hardly any bandwidth); events order table reuse.
@@ -217,7 +220,8 @@ bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t
 // `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
 // 2 = only the store stream (used to time the dominant kernel on its own).
 int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
-                size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0, double accuracy = 0.0) {
+                size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0, double accuracy = 0.0,
+                double* d_stats = nullptr) {
   if (row_count == 0 || N1 == 0) return INFLX_OK;
   InflxSweepArgs a;
   memset(&a, 0, sizeof a);
@@ -235,6 +239,7 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   a.layout = (uint32_t)layout;
   a.col_chunks = 1;
   a.accuracy = accuracy;
+  a.stats = d_stats;  // non-NULL: complete_analysis with the running summary (d_out may then be NULL)
   void* params[] = {&a};
   // the flag sweep reads the basis vector, whose axis dependence the out_mask does not describe
   const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
@@ -261,22 +266,24 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
       const size_t pb = std::min(batch, P - p0);
       // `what` == 2 (timing only) re-runs the store streams from whatever the tables hold
       const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
-      int rc = ensure_row_table(m, b, pb * row_count * replicas * 8);
+      const bool store = d_out != nullptr;
+      int rc = store ? ensure_row_table(m, b, pb * row_count * replicas * 8) : INFLX_OK;
       if (rc) return rc;
       a.params = d_params + p0 * m->n_par;
-      a.out = d_out + p0 * row_count * N1 * K;  // same offset for [P][rows][N1][K] and [P][K][rows][N1]
+      a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;  // same offset for [P][rows][N1][K] and [P][K][rows][N1]
       a.P = (uint32_t)pb;
-      a.row_table = m->d_row_table[b];
+      a.row_table = store ? m->d_row_table[b] : nullptr;
       a.table_replicas = (uint32_t)replicas;
       a.stream_planes = (uint32_t)K;
       if (what != 2) {
         // per-row evaluation on the side stream, as soon as the previous reader of this table is done
         if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
-        HIP_TRY(hipModuleLaunchKernel(m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0, m->side, params, nullptr));
+        HIP_TRY(hipModuleLaunchKernel(d_stats ? m->rowvals_stats : m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0,
+                                      m->side, params, nullptr));
         HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
         m->table_turn++;
       }
-      if (what != 1) {
+      if (what != 1 && store) {
         HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
         // grid.y is limited to 65535, longer slabs take several launches
         for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
@@ -308,8 +315,8 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     const size_t gy = (row_count + m->info.tile_rows - 1) / m->info.tile_rows;
     if (gy > 65535 || gx > 0x7fffffffULL)
       return fail(INFLX_ERR_SHAPE, "grid too large for one launch (%zu x %zu tiles); sweep fewer rows per call", gx, gy);
-    HIP_TRY(hipModuleLaunchKernel(m->tile[op], (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params,
-                                  nullptr));
+    hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
+    HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
   }
   return INFLX_OK;
 }
@@ -430,6 +437,9 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
     }
   }
   if (hipModuleGetFunction(&m->rowstream6, m->module, "inflx_sweep_rowstream6") != hipSuccess ||
+      hipModuleGetFunction(&m->tile_stats, m->module, "inflx_sweep_tile_complete_stats") != hipSuccess ||
+      hipModuleGetFunction(&m->tile_stats_nostore, m->module, "inflx_sweep_tile_complete_stats_nostore") != hipSuccess ||
+      hipModuleGetFunction(&m->rowvals_stats, m->module, "inflx_sweep_rowvals_complete_stats") != hipSuccess ||
       hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
@@ -476,6 +486,7 @@ void inflx_close(inflx_model* m) {
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->d_params) (void)hipFree(m->d_params);
+  if (m->d_stats) (void)hipFree(m->d_stats);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->side) (void)hipStreamDestroy(m->side);
   if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
@@ -494,6 +505,39 @@ int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t*
   if (nr) *nr = m->info.n_row;
   if (nc) *nc = m->info.n_col;
   if (out_mask) *out_mask = m->info.out_mask;
+  return INFLX_OK;
+}
+
+int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes, const double* ss,
+                             size_t N0, size_t N1, size_t row_begin, size_t row_count, void* stream, inflx_summary* summary) {
+  const int op = INFLX_OP_COMPLETE;
+  int rc = validate(m, op, p, P, n_p);
+  if (rc) return rc;
+  if (!ss || !summary) return fail(INFLX_ERR_ARG, "start_stop / summary pointer is NULL");
+  if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
+  if (d_out && d_out_bytes < P * row_count * N1 * kOpBytes[op])
+    return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, P * row_count * N1 * kOpBytes[op]);
+  HIP_TRY(hipSetDevice(m->device));
+  hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+  const bool row_path = takes_row_stream(m, op, INFLX_AOS, P, N1);
+  hipStream_t eval = row_path ? m->side : s;  // the stream of the kernels that accumulate
+  if (!m->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), 18 * sizeof(double)));
+  inflx_summary init;
+  for (int k = 0; k < 6; ++k) {
+    init.min[k] = HUGE_VAL;
+    init.max[k] = -HUGE_VAL;
+    init.count[k] = 0;
+  }
+  static_assert(sizeof(inflx_summary) == 18 * 8, "inflx_summary must match the device layout");
+  HIP_TRY(hipMemcpyAsync(m->d_stats, &init, sizeof init, hipMemcpyHostToDevice, eval));
+  if ((rc = ensure_params(m, p, P * n_p, eval))) return rc;
+  if (row_count && N1) {
+    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, INFLX_AOS, s, 0, 0.0, m->d_stats);
+    if (rc) return rc;
+  }
+  HIP_TRY(hipMemcpyAsync(summary, m->d_stats, sizeof *summary, hipMemcpyDeviceToHost, eval));
+  HIP_TRY(hipStreamSynchronize(eval));
+  if (eval != s) HIP_TRY(hipStreamSynchronize(s));
   return INFLX_OK;
 }
 

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 8u
+#define INFLX_KERNEL_ABI 9u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -48,6 +48,9 @@ struct InflxSweepArgs {
   uint32_t table_replicas;
   uint32_t stream_planes;  // inflx_sweep_rowstream_planes: K, the number of result planes per parameter row
   double accuracy;  // INFLX_OP_QDIF: threshold of ops::flag_quantum_diff
+  // *_stats kernels: running summary of the six outputs over everything the launch evaluates --
+  // [0..5] NaN-ignoring minimum, [6..11] NaN-ignoring maximum (f64), [12..17] number of non-NaN values (u64)
+  double* stats;
 };
 
 // Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch

@@ -54,10 +54,6 @@
 #ifndef INFLX_MIN_WAVES
 #define INFLX_MIN_WAVES 2
 #endif
-// tile kernels: unroll factor of the loop over the tile's rows (1 = none)
-#ifndef INFLX_ROW_UNROLL
-#define INFLX_ROW_UNROLL 1
-#endif
 // tile kernels: keep the parameter-only (U) values in LDS instead of 2 VGPRs each
 #ifndef INFLX_U_IN_LDS
 #define INFLX_U_IN_LDS (INFLX_NU > 8)
@@ -152,12 +148,67 @@ __device__ __forceinline__ void load_params(const double* __restrict__ params, u
   for (int k = 0; k < INFLX_N_PARAMETERS; ++k) A[k] = params[(size_t)p * INFLX_N_PARAMETERS + k];
 }
 
+// ---- running summary of the six outputs (the "consistency mask" statistics: where does the condition
+// ---- hold, what range do epsilon_H, eta, omega take) -- fused into the sweep, no second pass over HBM
+struct StatAcc {
+  double mn[6], mx[6];
+  unsigned long long cnt[6];
+};
+
+__device__ __forceinline__ void stat_init(StatAcc& s) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    s.mn[k] = __builtin_inf();
+    s.mx[k] = -__builtin_inf();
+    s.cnt[k] = 0;
+  }
+}
+
+// NaN-ignoring (like np.nanmin / np.nanmax, reference tests/test_doc.py:58); +-Inf count as values
+__device__ __forceinline__ void stat_add(StatAcc& s, const double* o, unsigned long long weight) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (o[k] == o[k]) {
+      s.mn[k] = fmin(s.mn[k], o[k]);
+      s.mx[k] = fmax(s.mx[k], o[k]);
+      s.cnt[k] += weight;
+    }
+  }
+}
+
+// wave-wide butterfly reduction over the 64 lanes, then one set of device-scope atomics per wavefront
+__device__ __forceinline__ void stat_flush(StatAcc& s, double* stats) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int off = kWave / 2; off > 0; off >>= 1) {
+      s.mn[k] = fmin(s.mn[k], __shfl_xor(s.mn[k], off, kWave));
+      s.mx[k] = fmax(s.mx[k], __shfl_xor(s.mx[k], off, kWave));
+      s.cnt[k] += __shfl_xor(s.cnt[k], off, kWave);
+    }
+  }
+  if ((threadIdx.x & (kWave - 1)) == 0) {
+    unsigned long long* counts = reinterpret_cast<unsigned long long*>(stats + 12);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      if (s.cnt[k]) {
+        __hip_atomic_fetch_min(stats + k, s.mn[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_max(stats + 6 + k, s.mx[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(counts + k, s.cnt[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+}
+
 // ================================================================================================
 // tile kernels: general case (some value depends on x[1])
 // ================================================================================================
-template <int OP>
+template <int OP, bool STATS = false, bool STORE = true>
 __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   constexpr int K = OpWidth<OP>::K;
+  static_assert(!STATS || OP == INFLX_OP_COMPLETE, "the summary is defined for the six outputs of complete_analysis");
+  StatAcc acc;
+  if constexpr (STATS) stat_init(acc);
   __shared__ double Rs[kTileRows][kNR];
   __shared__ __attribute__((aligned(16))) double tbuf[kThreads / kWave][kWave * 6];
 
@@ -200,14 +251,17 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const uint64_t cols_left = wave_col0 < a.N1 ? a.N1 - wave_col0 : 0;
   const unsigned wave_units = cols_left >= kWave ? 3u * kWave : 3u * (unsigned)cols_left;
 
-#pragma unroll INFLX_ROW_UNROLL
-  for (int r = 0; r < nrows; ++r) {
+  for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
     const uint64_t row = row0 + r;
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
     InflxModelValues mv;
     inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
     double o[K];
     apply_op<OP>(mv, o, a.accuracy);
+    if constexpr (STATS) {
+      if (in_range) stat_add(acc, o, 1);
+    }
+    if constexpr (!STORE) continue;
 
     if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
       if (in_range) {
@@ -247,6 +301,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       }
     }
   }
+  if constexpr (STATS) stat_flush(acc, a.stats);
 }
 
 // ================================================================================================
@@ -279,7 +334,7 @@ __device__ __forceinline__ void eval_row(const InflxSweepArgs& a, unsigned p, ui
 //     this shape 6.8-6.9 TB/s, hipMemsetAsync 6.5, several stores per thread 5.2-5.9 (one wavefront per
 //     row, grid-stride chunks, 8-96 KiB per workgroup), non-temporal pairs of adjacent stores 2.1.
 //     The row's values arrive by scalar loads (the table address is workgroup-uniform).
-template <int OP>
+template <int OP, bool STATS = false>
 __device__ __forceinline__ void sweep_rowvals(const InflxSweepArgs& a) {
   // one wavefront per workgroup (launched with 64 threads): 64 grid rows, spread over as many CUs as
   // possible because the evaluation is a ~750-instruction dependent chain per lane (latency-bound)
@@ -290,6 +345,14 @@ __device__ __forceinline__ void sweep_rowvals(const InflxSweepArgs& a) {
   const unsigned p = blockIdx.y;
   double o[8] = {0., 0., 0., 0., 0., 0., 0., 0.};
   if (row0 + lane < a.row_count) eval_row<OP>(a, p, row0 + lane, o);
+  if constexpr (STATS) {
+    // every point of the row has these six values: the row counts N1 times
+    StatAcc acc;
+    stat_init(acc);
+    if (row0 + lane < a.row_count) stat_add(acc, o, a.N1);
+    stat_flush(acc, a.stats);
+    if (a.row_table == nullptr) return;  // summary-only sweep: nothing to broadcast
+  }
 #pragma unroll
   for (int k = 0; k < 8; ++k) vals[lane][k] = o[k];
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -436,6 +499,16 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   }
 
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
+// complete_analysis with the running summary; the *_nostore variant evaluates and reduces only
+extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_complete_stats(const InflxSweepArgs a) {
+  sweep_tile<INFLX_OP_COMPLETE, true, true>(a);
+}
+extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_complete_stats_nostore(const InflxSweepArgs a) {
+  sweep_tile<INFLX_OP_COMPLETE, true, false>(a);
+}
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowvals_complete_stats(const InflxSweepArgs a) {
+  if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rowvals<INFLX_OP_COMPLETE, true>(a);
+}
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream_planes(const InflxSweepArgs a) {
   sweep_rowstream_planes(a);
 }

@@ -139,3 +139,29 @@ class HipCompute:
             consumer.wait_stream(self.stream)  # whatever torch does next with `out` (e.g. the all-gather) is ordered after the sweep
             out.record_stream(self.stream)
         return out
+
+
+def numpy_summary(block: np.ndarray) -> dict:
+    """The summary of a (..., 6) result block computed with numpy (what the device reduction must equal)."""
+    flat = np.asarray(block, dtype=np.float64).reshape(-1, 6)
+    ok = ~np.isnan(flat)
+    with np.errstate(all="ignore"):
+        mn = np.where(ok.any(axis=0), np.nanmin(np.where(ok, flat, np.inf), axis=0), np.inf)
+        mx = np.where(ok.any(axis=0), np.nanmax(np.where(ok, flat, -np.inf), axis=0), -np.inf)
+    return {"min": mn, "max": mx, "count": ok.sum(axis=0).astype(np.uint64)}
+
+
+def all_reduce_summary(summary: dict, device=None, group=None) -> dict:
+    """Combine the per-rank summaries of a sharded sweep: three tiny all-reduces (MIN, MAX, SUM) of six
+    numbers each -- the only exchange a sharded sweep needs when the caller wants statistics rather than
+    the arrays (RCCL when ``device`` is a GPU, gloo on the CPU)."""
+    import torch
+    import torch.distributed as dist
+
+    mn = torch.tensor(np.asarray(summary["min"], dtype=np.float64), device=device)
+    mx = torch.tensor(np.asarray(summary["max"], dtype=np.float64), device=device)
+    cnt = torch.tensor(np.asarray(summary["count"]).astype(np.int64), device=device)
+    dist.all_reduce(mn, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    dist.all_reduce(cnt, op=dist.ReduceOp.SUM, group=group)
+    return {"min": mn.cpu().numpy(), "max": mx.cpu().numpy(), "count": cnt.cpu().numpy().astype(np.uint64)}

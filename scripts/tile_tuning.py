@@ -17,9 +17,8 @@ stream = torch.cuda.current_stream().cuda_stream
 out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
 for name in models:
     spec = example_models.get(name)
-    for waves, ulds, rows in itertools.product((1, 2), (1, 2), (32,)):
-        # second knob reused here: store flavour (1 = non-temporal, 0 = plain)
-        flags = Compiler.default_hipcc_flags + [f"-DINFLX_MIN_WAVES={waves}", f"-DINFLX_ROW_UNROLL={ulds}", f"-DINFLX_TILE_ROWS={rows}"]
+    for waves, ulds, rows in itertools.product((1, 2, 3), (0, 1), (16, 32, 64)):
+        flags = Compiler.default_hipcc_flags + [f"-DINFLX_MIN_WAVES={waves}", f"-DINFLX_U_IN_LDS={ulds}", f"-DINFLX_TILE_ROWS={rows}"]
         try:
             art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, **spec.compiler_kwargs).compile()
         except Exception as exc:  # noqa: BLE001
@@ -27,4 +26,4 @@ for name in models:
             continue
         lib = _native.InflatoxDevLib(art.shared_object_path)
         ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=stream, repeats=10) for _ in range(3))
-        print(f"{name:8s} min_waves={waves} row_unroll={ulds} tile_rows={rows}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
+        print(f"{name:8s} min_waves={waves} u_in_lds={ulds} tile_rows={rows}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)

@@ -9,7 +9,7 @@ import socket
 import numpy as np
 import pytest
 
-from inflatox_amd.distributed import ShardedSweep, block_bounds, plan_shard
+from inflatox_amd.distributed import ShardedSweep, all_reduce_summary, block_bounds, numpy_summary, plan_shard
 
 
 def test_block_bounds_cover_everything_once():
@@ -72,6 +72,11 @@ def _worker(rank, world, port, case, tmpdir):
             assert np.array_equal(local, want[plan2.p_begin : plan2.p_begin + plan2.p_count], equal_nan=True)
         else:
             assert np.array_equal(local, want[:, plan2.row_begin : plan2.row_begin + plan2.row_count], equal_nan=True)
+        # statistics instead of arrays: per-rank summaries combined by three six-element all-reduces
+        combined = all_reduce_summary(numpy_summary(local))
+        whole = numpy_summary(want)
+        assert np.array_equal(combined["min"], whole["min"]) and np.array_equal(combined["max"], whole["max"])
+        assert np.array_equal(combined["count"], whole["count"])
         open(os.path.join(tmpdir, f"ok_{rank}"), "w").write(plan.axis)
     finally:
         dist.destroy_process_group()

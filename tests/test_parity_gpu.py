@@ -373,3 +373,33 @@ def test_sharded_sweep_with_hip_compute(gpu_lib):
     # a rank that owns rows [40, 70) only
     part = HipCompute(lib, spec.extent, n0, n1)(rows, 40, 30)
     assert np.array_equal(part.cpu().numpy(), want[:, 40:70], equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["doc", "hyperbolic", "d5"])
+def test_fused_summary_equals_numpy_over_the_arrays(name, gpu_lib):
+    """inflx_sweep_device_stats: min / max / non-NaN count reduced inside the sweep kernels (wave
+    butterfly + f64 atomics) must equal numpy's nanmin / nanmax / count over the arrays the same sweep
+    writes -- with the arrays stored, and in the summary-only mode that writes nothing."""
+    import torch
+
+    from inflatox_amd.distributed import numpy_summary
+
+    spec, art, lib = devlib(name, gpu_lib)
+    n0, n1 = 301, 517
+    rows = np.stack([spec.args, spec.args * (1.0 + 0.05 * np.arange(len(spec.args)))])
+    for p in (spec.args, rows):
+        arrays = lib.sweep_host(gpu_lib.OP_COMPLETE, p, spec.extent, n0, n1)
+        want = numpy_summary(arrays)
+        only = lib.sweep_stats(p, spec.extent, n0, n1)
+        P = 1 if np.ndim(p) == 1 else len(p)
+        out = torch.empty((P, n0, n1, 6), dtype=torch.float64, device="cuda:0")
+        both = lib.sweep_stats(p, spec.extent, n0, n1, d_out_ptr=out.data_ptr(), d_out_bytes=out.numel() * 8)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(arrays.shape), arrays, equal_nan=True)
+        for got in (only, both):
+            assert np.array_equal(got["count"], want["count"]), (name, got["count"], want["count"])
+            assert np.array_equal(got["min"], want["min"]) and np.array_equal(got["max"], want["max"]), (name, got, want)
+    # a row range only (what a rank of a row-sharded sweep reduces)
+    part = lib.sweep_stats(spec.args, spec.extent, n0, n1, row_begin=100, row_count=57)
+    want = numpy_summary(lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1, row_begin=100, row_count=57))
+    assert np.array_equal(part["count"], want["count"]) and np.array_equal(part["min"], want["min"]) and np.array_equal(part["max"], want["max"])
