@@ -180,6 +180,24 @@ def main():
     points = N0 * N1
     achieved = BYTES_PER_POINT * points / (ms_kernel * 1e-3) / 1e9
 
+    # outside the timed region: the statistics path of a sharded sweep -- every rank reduces its own block
+    # on the device (summary-only sweep), three six-element all-reduces combine the ranks (RCCL when N > 1)
+    stats_info = None
+    try:
+        t0 = time.perf_counter()
+        local = lib.sweep_stats(args, spec.extent, N0, N1)
+        if distributed:
+            from inflatox_amd.distributed import all_reduce_summary
+
+            local = all_reduce_summary(local, device=f"cuda:{local_rank}")
+        stats_info = {
+            "ms": (time.perf_counter() - t0) * 1e3,
+            "nanmax": [None if not np.isfinite(v) else float(v) for v in local["max"]],
+            "non_nan": [int(v) for v in local["count"]],
+        }
+    except Exception as exc:  # noqa: BLE001 -- never let the optional extra break the benchmark line
+        stats_info = {"error": str(exc)[:200]}
+
     if rank == 0:
         kernel = "inflx_sweep_rowstream6" if row_path else "inflx_sweep_tile_complete"
         line = {
@@ -214,6 +232,7 @@ def main():
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * points,
             },
         }
+        line["summary_sweep"] = stats_info
         if world == 1 and not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(opt.model, spec.args, spec.extent)
         print(json.dumps(line), flush=True)
