@@ -358,8 +358,11 @@ class Compiler:
         log = b""
         code = 0
         if not os.path.exists(cached):
-            with open(header_path, "w") as fh:
+            # several ranks may compile the same model at once: every file appears atomically
+            tmp_hdr = header_path + f".{os.getpid()}.tmp"
+            with open(tmp_hdr, "w") as fh:
                 fh.write(header_text)
+            os.replace(tmp_hdr, header_path)
             tmp_out = cached + f".{os.getpid()}.tmp"
             cmd = [hipcc_path(), *opts, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
             proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
