@@ -32,8 +32,9 @@ typedef enum inflx_status {
   INFLX_ERR_VERSION = 3, /* artefact built for another ABI version -> SystemError  (err.rs:70)    */
   INFLX_ERR_SHAPE = 4,   /* array shape / parameter count mismatch -> Exception    (err.rs:71)    */
   INFLX_ERR_DEVICE = 5,  /* HIP runtime failure (no counterpart)   -> SystemError                 */
-  INFLX_ERR_ARG = 6      /* invalid argument (NULL, bad enum)      -> ValueError; the reference
+  INFLX_ERR_ARG = 6,     /* invalid argument (NULL, bad enum)      -> ValueError; the reference
                             panics on the analogous conditions (anguelova.rs:473,501)             */
+  INFLX_ERR_BASIS = 7    /* basis not orthonormal (BasisNorm/BasisOth) -> Exception (err.rs:36-37,72) */
 } inflx_status;
 
 /* per-point operation selector; numbering shared with the kernels (csrc/inflx_kernel_abi.h) */
@@ -101,6 +102,22 @@ int inflx_flag_quantum_dif(inflx_model* model, const double* p, size_t n_p, uint
 /* on-trajectory variants (src/anguelova.rs:633-977): x is (n,2), out is (n,K) */
 int inflx_sweep_on_trajectory(inflx_model* model, int op, const double* p, size_t n_p, const double* x, size_t n,
                               double* out, int progress, size_t threads);
+
+/*
+ * Basis validation (src/lib.rs:141-300).  The reference calls the artefact's C functions `v`, `w1` and
+ * `inner_prod` (compiler.py:417-472) point by point; here one launch evaluates them at n explicit points.
+ *   inflx_basis_on_points: x is (n,2); out is (n,7): v.v, v.w1, w1.w1, v[0], v[1], w1[0], w1[1]
+ *   inflx_validate_basis_at_random (lib.rs:142-199, run by open_inflx_dylib(check_basis=true), lib.rs:109-114):
+ *     one random parameter vector in [-10,10), 100 random points in [-1,1)^2, accuracy 1e-3;
+ *     seed 0 = seed from the OS (the reference's rand::random), any other value = reproducible
+ *   inflx_validate_basis_on_domain (lib.rs:207-300): num_points is (n_axes,), start_stop (n_axes,2) row-major
+ * Both return INFLX_ERR_BASIS with the reference's message when a norm or overlap misses its target by
+ * >= accuracy, and print the reference's warnings for inner products that are not normal numbers.
+ */
+int inflx_basis_on_points(inflx_model* model, const double* p, size_t n_p, const double* x, size_t n, double* out);
+int inflx_validate_basis_at_random(inflx_model* model, uint64_t seed);
+int inflx_validate_basis_on_domain(inflx_model* model, const uint32_t* num_points, size_t n_axes, const double* p,
+                                   size_t n_p, const double* start_stop, double accuracy);
 
 /*
  * Generalised sweep, host result.  P parameter rows (p is (P,n_p)), grid rows

@@ -17,7 +17,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libinflx_hip.so")
 
-OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG = range(7)
+OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG, ERR_BASIS = range(8)
 
 OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
 OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5}
@@ -57,6 +57,9 @@ SIGNATURES = {
         [C.c_void_p, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_void_p, C.c_void_p],
     ),
     "inflx_synchronize": (C.c_int, [C.c_void_p]),
+    "inflx_basis_on_points": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _SIZE, _DP]),
+    "inflx_validate_basis_at_random": (C.c_int, [C.c_void_p, C.c_uint64]),
+    "inflx_validate_basis_on_domain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _SIZE, _DP, _SIZE, _DP, C.c_double]),
 }
 
 
@@ -139,6 +142,10 @@ class InflatoxShapeError(Exception):
     """Counterpart of LibInflxRsErr::Shape, which PyO3 raises as a plain Exception (err.rs:71)."""
 
 
+class InflatoxBasisError(Exception):
+    """Counterpart of LibInflxRsErr::BasisNorm / BasisOth (err.rs:36-37), plain Exceptions in PyO3 too."""
+
+
 def _raise(rc: int):
     msg = load_library().inflx_last_error().decode("utf-8", "replace")
     if rc == ERR_IO:
@@ -147,6 +154,8 @@ def _raise(rc: int):
         raise SystemError(msg)
     if rc == ERR_SHAPE:
         raise InflatoxShapeError(msg)
+    if rc == ERR_BASIS:
+        raise InflatoxBasisError(msg)
     raise ValueError(msg)
 
 
@@ -254,6 +263,33 @@ class InflatoxDevLib:
         _check(self._lib.inflx_sweep_on_trajectory(self._h, op, _ptr(p), p.size, _ptr(x), x.shape[0], _ptr(out), int(bool(progress)), int(threads)))
         return out
 
+    # ---- basis validation (src/lib.rs:141-300) --------------------------------------------------
+    def basis_on_points(self, p, x) -> np.ndarray:
+        """(n,7): v.v, v.w1, w1.w1, v[0], v[1], w1[0], w1[1] at the points ``x`` (n,2)."""
+        p = _f64(p, "p").reshape(-1)
+        x = _f64(x, "x")
+        if x.ndim != 2 or x.shape[1] != 2:
+            raise InflatoxShapeError(f"point array should have shape (n,2) (got {x.shape})")
+        out = np.zeros((x.shape[0], 7))
+        _check(self._lib.inflx_basis_on_points(self._h, _ptr(p), p.size, _ptr(x), x.shape[0], _ptr(out)))
+        return out
+
+    def validate_basis_at_random(self, seed: int = 0) -> None:
+        _check(self._lib.inflx_validate_basis_at_random(self._h, int(seed)))
+
+    def validate_basis_on_domain(self, num_points, p, start_stop, accuracy) -> None:
+        """``validate_basis_on_domain(num_points, p, start_stop, accuracy)`` of src/lib.rs:207-212."""
+        n = np.ascontiguousarray(num_points, dtype=np.uint32).reshape(-1)
+        p = _f64(p, "p").reshape(-1)
+        ss = _f64(start_stop, "start_stop")
+        if ss.ndim != 2 or ss.shape[1] != 2 or ss.shape[0] != n.size:
+            raise InflatoxShapeError(f"start_stop array should have 2 rows and as many columns as there are fields (got {ss.shape})")
+        _check(
+            self._lib.inflx_validate_basis_on_domain(
+                self._h, n.ctypes.data_as(C.POINTER(C.c_uint32)), n.size, _ptr(p), p.size, _ptr(ss), float(accuracy)
+            )
+        )
+
     # ---- generalised sweeps -------------------------------------------------------------------
     def sweep_host(self, op, p, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS) -> np.ndarray:
         """P parameter rows x rows [row_begin,row_begin+row_count) of the grid -> host ndarray."""
@@ -322,7 +358,11 @@ class InflatoxDevLib:
 def open_inflx_dylib(lib_path: str, check_basis: bool = True, device: int = 0) -> InflatoxDevLib:
     """Counterpart of ``libinflx_rs.open_inflx_dylib(lib_path, check_basis)`` (src/lib.rs:108-115).
 
-    The random-point basis check (lib.rs:142-202) is a load-time guard outside the sweep path and is
-    not performed on the device; ``check_basis`` is accepted for signature compatibility.
+    With ``check_basis`` the basis vectors of the artefact are evaluated on the device at 100 random
+    points for one random parameter vector and tested for orthonormality (lib.rs:142-199); a defective
+    basis raises :class:`InflatoxBasisError` (a plain ``Exception``, as in the reference).
     """
-    return InflatoxDevLib(lib_path, device=device)
+    lib = InflatoxDevLib(lib_path, device=device)
+    if check_basis:
+        lib.validate_basis_at_random()
+    return lib

@@ -64,12 +64,26 @@ class InflationCondition:
         raw = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N)
         return np.stack([np.stack([raw[1], raw[2]]), np.stack([raw[2], raw[3]])])
 
+    def validate_basis_on_domain(self, args, start, stop, N=100, accuracy: float = 1e-3) -> None:
+        """Checks that the basis {v, w1} is orthonormal (to ``accuracy``) on sample points of the domain
+        and raises an exception if it is not (reference consistency_conditions.py:158-196,
+        src/lib.rs:207-300).  The sample points are the reference's: each axis in turn is walked in
+        ``N[axis]`` steps of ``(stop-start)/N`` beginning at its *stop* value (lib.rs:252), the other
+        coordinate held at its start value.  An ``int`` N applies to both axes (the reference intends
+        that, consistency_conditions.py:194, but its ``N is int`` test never fires)."""
+        n_fields = self.artifact.n_fields
+        start_stop = np.array([[float(a), float(b)] for (a, b) in zip(start, stop)])
+        if isinstance(N, (int, np.integer)):
+            N = [int(N)] * n_fields
+        self.dylib.validate_basis_on_domain(N, args, start_stop, accuracy)
+
 
 class GeneralisedAL(InflationCondition):
     """Generalised Anguelova-Lazaroiu consistency condition and the quantities derived from it
     (reference consistency_conditions.py:199-715)."""
 
     def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0):
+        # like the reference (consistency_conditions.py:222-224 -> :38), the constructor validates the basis
         super().__init__(compiled_artifact, device=device)
 
     # ---- the hot path ------------------------------------------------------------------------

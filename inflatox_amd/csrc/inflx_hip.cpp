@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <future>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -113,6 +114,7 @@ struct inflx_model {
   hipFunction_t tile[INFLX_OP_COUNT] = {};
   hipFunction_t rows[INFLX_OP_COUNT] = {};
   hipFunction_t traj[INFLX_OP_COUNT] = {};
+  hipFunction_t basis_points = nullptr;
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
   hipFunction_t rowstream_planes = nullptr;
@@ -342,6 +344,75 @@ void say(const char* fmt, ...) {
   va_end(ap);
 }
 
+void warn(const char* fmt, ...) {
+  // BADGE_WARN lines (src/lib.rs:58-61)
+  va_list ap;
+  va_start(ap, fmt);
+  fputs("[Inflatox Warning] ", stderr);
+  vfprintf(stderr, fmt, ap);
+  fputc('\n', stderr);
+  fflush(stderr);
+  va_end(ap);
+}
+
+std::string list_text(const double* v, size_t n) {
+  // Rust's {:.03?} of a Vec<f64>
+  std::string s = "[";
+  char buf[64];
+  for (size_t k = 0; k < n; ++k) {
+    snprintf(buf, sizeof buf, "%s%.3f", k ? ", " : "", v[k]);
+    s += buf;
+  }
+  return s + "]";
+}
+
+double unit_random(uint64_t& state) {
+  // splitmix64 -> [0, 1) with 53 random bits; the reference draws from rand::random::<f64>() (thread_rng,
+  // unseeded), so no particular sequence is part of its behaviour
+  uint64_t z = (state += 0x9E3779B97F4A7C15ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  return (double)(z >> 11) * 0x1.0p-53;
+}
+
+// The orthonormality test of src/lib.rs:164-193 (= :262-285) over the 7-double records of
+// inflx_basis_on_points; `failed` counts points at which an inner product was not a normal number.
+int check_basis(const double* basis, const double* x, size_t n, double accuracy, size_t* failed) {
+  for (size_t k = 0; k < n; ++k) {
+    const double* b = basis + 7 * k;
+    const std::string point = list_text(x + 2 * k, 2);
+    bool encountered_nan = false;
+    const int pair[3][2] = {{0, 0}, {0, 1}, {1, 1}};
+    for (int q = 0; q < 3; ++q) {
+      const int i = pair[q][0], j = pair[q][1];
+      const double ip = b[q];
+      const std::string vi = list_text(b + 3 + 2 * i, 2), vj = list_text(b + 3 + 2 * j, 2);
+      if (i == j) {
+        if (!std::isnormal(ip)) {
+          warn("Norm of basisvector %d is %g at field-space point %s. v%d=%s\nAre we outside the model's domain?", i, ip,
+               point.c_str(), i, vi.c_str());
+          encountered_nan = true;
+        } else if (std::fabs(ip - 1.) >= accuracy) {
+          return fail(INFLX_ERR_BASIS, "Expected basis vector %d to be normalised everywhere in the models domain. Instead, "
+                      "found norm %g at %s.", i, ip, point.c_str());
+        }
+      } else {
+        if (!std::isnormal(ip) && ip != 0.0) {
+          warn("w%d•w%d = %g at field-space point %s.\nv%d=%s\nv%d=%s\nAre we outside the model's domain?", i, j, ip,
+               point.c_str(), i, vi.c_str(), j, vj.c_str());
+          encountered_nan = true;
+        } else if (std::fabs(ip) >= accuracy) {
+          return fail(INFLX_ERR_BASIS, "Expected basis vectors w%d and w%d to be orthogonal everywhere in the model's domain. "
+                      "Instead, found inner product %g at %s.", i, j, ip, point.c_str());
+        }
+      }
+    }
+    if (encountered_nan) ++*failed;
+  }
+  return INFLX_OK;
+}
+
 int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
                int progress, const char* what) {
   if (!out) return fail(INFLX_ERR_ARG, "output array is NULL");
@@ -442,6 +513,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
       hipModuleGetFunction(&m->rowvals_stats, m->module, "inflx_sweep_rowvals_complete_stats") != hipSuccess ||
       hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
+    return bail(INFLX_ERR_SYMBOL);
+  }
+  if (hipModuleGetFunction(&m->basis_points, m->module, "inflx_basis_points") != hipSuccess) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_basis_points", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
@@ -587,6 +662,85 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, m->t0, m->t1));
   *ms_per_launch = ms / (float)repeats;
+  return INFLX_OK;
+}
+
+int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const double* x, size_t n, double* out) {
+  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p);
+  if (rc) return rc;
+  if (n == 0) return INFLX_OK;
+  if (!x || !out) return fail(INFLX_ERR_ARG, "point / output pointer is NULL");
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t in_bytes = n * 2 * sizeof(double), out_bytes = n * 7 * sizeof(double);
+  if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
+  if ((rc = ensure_chunk(m, 1, in_bytes))) return rc;
+  if ((rc = ensure_params(m, p, n_p, m->stream))) return rc;
+  HIP_TRY(hipMemcpyAsync(m->d_chunk[1], x, in_bytes, hipMemcpyHostToDevice, m->stream));
+  InflxTrajectoryArgs a;
+  memset(&a, 0, sizeof a);
+  a.out = static_cast<double*>(m->d_chunk[0]);
+  a.params = m->d_params;
+  a.points = static_cast<const double*>(m->d_chunk[1]);
+  a.n = n;
+  a.P = 1;
+  void* params[] = {&a};
+  const size_t gx = (n + m->info.tile_cols - 1) / m->info.tile_cols;
+  HIP_TRY(hipModuleLaunchKernel(m->basis_points, (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
+  HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+int inflx_validate_basis_at_random(inflx_model* m, uint64_t seed) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  // src/lib.rs:142-162: one random parameter vector in [-10, 10), 100 random points in [-1, 1)^2
+  const size_t num_points = 100;
+  uint64_t state = seed ? seed : (((uint64_t)std::random_device{}() << 32) ^ std::random_device{}());
+  std::vector<double> p(m->n_par), x(2 * num_points);
+  for (double& v : p) v = 10. * (-1. + 2. * unit_random(state));
+  for (double& v : x) v = -1. + 2. * unit_random(state);
+  std::vector<double> basis(7 * num_points);
+  int rc = inflx_basis_on_points(m, p.data(), p.size(), x.data(), num_points, basis.data());
+  if (rc) return rc;
+  size_t failed = 0;
+  if ((rc = check_basis(basis.data(), x.data(), num_points, 1e-3, &failed))) return rc;
+  if (failed)
+    warn("Inflatox was unable to verify basis orthonormality at %zu out of %zu tested points.\nThis could be indicative of a "
+         "defective model.\nUsed parameter values: p=%s", failed, num_points, list_text(p.data(), p.size()).c_str());
+  return INFLX_OK;
+}
+
+int inflx_validate_basis_on_domain(inflx_model* m, const uint32_t* num_points, size_t n_axes, const double* p, size_t n_p,
+                                   const double* ss, double accuracy) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (!num_points || !ss) return fail(INFLX_ERR_ARG, "num_points / start_stop array is NULL");
+  say("Validating basis orthonormality on specified domain. This may take a while...");
+  if (n_axes != m->dim)
+    return fail(INFLX_ERR_SHAPE, "expected an array with with the same number of axes as there are field-space coordinates "
+                "(model has %u fields, got %zu)", m->dim, n_axes);
+  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p);
+  if (rc) return rc;
+  // src/lib.rs:247-256: every axis in turn is walked from the START corner of the other axis; the walk
+  // itself begins at that axis' STOP value (`stop + spacing * idx`) -- reproduced as the reference has it
+  size_t failed = 0;
+  double tested = 1.;
+  for (size_t k = 0; k < n_axes; ++k) tested *= (double)num_points[k];
+  for (size_t axis = 0; axis < n_axes; ++axis) {
+    const size_t n = num_points[axis];
+    const double start = ss[2 * axis], stop = ss[2 * axis + 1];
+    const double spacing = (stop - start) / (double)n;
+    std::vector<double> x(2 * n), basis(7 * n);
+    for (size_t idx = 0; idx < n; ++idx) {
+      x[2 * idx] = ss[0];
+      x[2 * idx + 1] = ss[2];
+      x[2 * idx + axis] = stop + spacing * (double)idx;
+    }
+    if ((rc = inflx_basis_on_points(m, p, n_p, x.data(), n, basis.data()))) return rc;
+    if ((rc = check_basis(basis.data(), x.data(), n, accuracy, &failed))) return rc;
+    if (failed)
+      warn("Inflatox was unable to verify basis orthonormality at %zu out of %g tested points.\nThis could be indicative of a "
+           "defective model.\nUsed parameter values: p=%s", failed, tested, list_text(p, n_p).c_str());
+  }
   return INFLX_OK;
 }
 

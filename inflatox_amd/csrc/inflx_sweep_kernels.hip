@@ -498,6 +498,19 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
     sweep_trajectory<OP>(a);                                                                             \
   }
 
+// validate_basis_*: v, w1 and their inner products at n explicit points, 7 doubles per point
+// (reference src/lib.rs:149-163 calls the C functions v, w1 and inner_prod per point)
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_basis_points(const InflxTrajectoryArgs a) {
+  const uint64_t idx = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  if (idx >= a.n) return;
+  double A[kNP];
+  load_params(a.params, blockIdx.y, A);
+  double o[7];
+  inflx_basis_point(a.points[2 * idx], a.points[2 * idx + 1], A, o);
+#pragma unroll
+  for (int k = 0; k < 7; ++k) a.out[((uint64_t)blockIdx.y * a.n + idx) * 7 + k] = o[k];
+}
+
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
 // complete_analysis with the running summary; the *_nostore variant evaluates and reduces only
 extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_complete_stats(const InflxSweepArgs a) {

@@ -593,5 +593,54 @@ def emit_stage_header(
         lines.append(f"  mv.{field} = {text};")
     out.append("\n".join(lines))
     out.append("}\n")
+    out.append(_emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector))
     info = dict(nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()})
     return "\n".join(out), info
+
+
+def _emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector):
+    """``inflx_basis_point``: the basis vectors ``v``, ``w1`` and their three metric inner products at one
+    point -- what ``validate_basis_*`` (reference src/lib.rs:141-300) obtains from the C functions ``v``,
+    ``w1`` and ``inner_prod`` (compiler.py:417-472).  Off the sweep path, so it is printed unstaged (one
+    self-contained function, evaluated per point) and, like the reference's ``inner_prod``, skips metric
+    components that print as zero and sums ``0.0 + (g_ij * v1[i] * v2[j]) + ...`` from left to right."""
+    dim = model.dim
+    vectors = [[sympy.sympify(c) for c in model.basis[k]] for k in range(dim)]
+    metric = [sympy.sympify(model.metric[i][j]) for i in range(dim) for j in range(dim)]
+    plain = C99CodePrinter()._print_Symbol
+    names = dict(names)
+    for sym in set().union(*[e.free_symbols for e in metric + [c for vec in vectors for c in vec]]) - {x0, x1}:
+        names[sym] = param_slots[plain(sym)]
+    functions = [cse_vector(vec) if cse_vector is not None else ([], vec) for vec in vectors]
+    functions.append(cse_vector(metric) if cse_vector is not None else ([], metric))
+    st = Stager(functions, x0, x1, names, staged=False)
+    lines = list(st.lines[P])
+    texts = list(st.outputs)
+    comps = ["bv", "bw"]
+    for k in range(dim):
+        for i in range(dim):
+            lines.append(f"  const double {comps[k]}{i} = {texts[k * dim + i]};")
+    gnames = {}
+    for i in range(dim):
+        for j in range(dim):
+            t = texts[dim * dim + i * dim + j]
+            if t in ("0", "0.0"):
+                continue
+            gnames[(i, j)] = f"g{i}{j}"
+            lines.append(f"  const double g{i}{j} = {t};")
+
+    def inner(a, b):
+        return "0.0" + "".join(f" + (g{i}{j} * {a}{i} * {b}{j})" for (i, j) in gnames)
+
+    lines += [
+        f"  o[0] = {inner('bv', 'bv')};",
+        f"  o[1] = {inner('bv', 'bw')};",
+        f"  o[2] = {inner('bw', 'bw')};",
+        "  o[3] = bv0; o[4] = bv1; o[5] = bw0; o[6] = bw1;",
+    ]
+    head = (
+        "// basis vectors v, w1 and their inner products v.v, v.w1, w1.w1 at one point (validate_basis_*)\n"
+        f"INFLX_FN void inflx_basis_point([[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {tail}, "
+        "double* __restrict__ o) {"
+    )
+    return head + "\n" + "\n".join(lines) + "\n}\n"

@@ -146,6 +146,82 @@ class OracleModel:
         return self.grid_sweep(OP.COMPLETE, p, extent, N0, N1, threads=threads)
 
 
+# ---- basis validation (reference src/lib.rs:141-300) --------------------------------------------
+import math
+
+
+class BasisDefect(Exception):
+    """LibInflxRsErr::BasisNorm / BasisOth (src/err.rs:36-37): ``kind`` is "norm" or "oth"."""
+
+    def __init__(self, kind, vectors, value, point):
+        super().__init__(f"{kind} {vectors} {value} at {point}")
+        self.kind, self.vectors, self.value, self.point = kind, vectors, value, point
+
+
+def basis_on_points(so_path: str, p, pts) -> np.ndarray:
+    """(n,7): v.v, v.w1, w1.w1, v[0], v[1], w1[0], w1[1], obtained the way src/lib.rs:164-169 does: the C
+    functions ``v``/``w1`` fill the vectors, ``inner_prod`` contracts them with the metric.  Small n only."""
+    so = C.CDLL(so_path)
+    dp = C.POINTER(C.c_double)
+    for name in ("v", "w1"):
+        getattr(so, name).argtypes = [dp, dp, dp]
+        getattr(so, name).restype = None
+    so.inner_prod.argtypes = [dp, dp, dp, dp]
+    so.inner_prod.restype = C.c_double
+    p = np.ascontiguousarray(p, dtype=np.float64)
+    pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
+    out = np.zeros((pts.shape[0], 7))
+    vec = [np.zeros(2), np.zeros(2)]
+    for k in range(pts.shape[0]):
+        x = np.ascontiguousarray(pts[k])
+        so.v(_dptr(x), _dptr(p), _dptr(vec[0]))
+        so.w1(_dptr(x), _dptr(p), _dptr(vec[1]))
+        for q, (i, j) in enumerate(((0, 0), (0, 1), (1, 1))):
+            out[k, q] = so.inner_prod(_dptr(x), _dptr(p), _dptr(vec[i]), _dptr(vec[j]))
+        out[k, 3:5], out[k, 5:7] = vec[0], vec[1]
+    return out
+
+
+def _is_normal(v: float) -> bool:
+    return math.isfinite(v) and abs(v) >= 2.2250738585072014e-308
+
+
+def check_basis(basis: np.ndarray, pts: np.ndarray, accuracy: float) -> int:
+    """The per-point tests of src/lib.rs:164-193; returns the number of points at which some inner
+    product was not a normal number, raises :class:`BasisDefect` at the first violation."""
+    failed = 0
+    for k in range(basis.shape[0]):
+        nan = False
+        for q, (i, j) in enumerate(((0, 0), (0, 1), (1, 1))):
+            ip = float(basis[k, q])
+            if i == j:
+                if not _is_normal(ip):
+                    nan = True
+                elif abs(ip - 1.0) >= accuracy:
+                    raise BasisDefect("norm", (i,), ip, tuple(pts[k]))
+            else:
+                if not _is_normal(ip) and ip != 0.0:
+                    nan = True
+                elif abs(ip) >= accuracy:
+                    raise BasisDefect("oth", (i, j), ip, tuple(pts[k]))
+        failed += nan
+    return failed
+
+
+def domain_points(num_points, start_stop) -> list:
+    """Sample points of ``validate_basis_on_domain`` (src/lib.rs:247-256), one (n,2) array per axis: the
+    walk along an axis starts at that axis' STOP value, the other coordinate sits at its start value."""
+    ss = np.asarray(start_stop, dtype=np.float64).reshape(-1, 2)
+    out = []
+    for axis, n in enumerate(num_points):
+        start, stop = ss[axis]
+        spacing = (stop - start) / float(n)
+        pts = np.tile(ss[:, 0], (int(n), 1))
+        pts[:, axis] = stop + spacing * np.arange(int(n), dtype=np.float64)
+        out.append(pts)
+    return out
+
+
 def raw_long_double(so_path_ld: str, p, pts) -> np.ndarray:
     """V, v00, v10, v11, |dV|^2 at the (n,2) points, evaluated in x87 extended precision by a model
     object built from ``emit_c_source(..., long_double=True)``; rounded to float64, shape (n,5)."""

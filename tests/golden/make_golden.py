@@ -219,5 +219,54 @@ def main(models):
     print("wrote symbols.json")
 
 
+def basis_goldens(models):
+    """tests/golden/basis.npz: the reference's C functions ``v``, ``w1`` and ``inner_prod`` (what
+    validate_basis_* calls, src/lib.rs:141-300) at seeded points -- 64 inside the model's extent at the
+    model's own parameters, and the 100 points in [-1,1)^2 with one parameter vector in [-10,10) that a
+    ``validate_basis_at_random`` run would draw."""
+    import subprocess
+
+    import joblib
+
+    from inflatox_amd import example_models
+    from oracle.cpu_oracle import basis_on_points
+    from oracle.model_c import REFERENCE_FLAGS
+
+    symbolic, compiler = load_reference()
+    tmp = tempfile.mkdtemp(prefix="inflx_golden_")
+    out = {}
+    for name in models:
+        spec = example_models.get(name)
+        print(f"== {name}: reference symbolic stage", flush=True)
+        with joblib.parallel_backend("sequential"):
+            builder = symbolic.InflationModelBuilder.new(
+                spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
+            )
+            model = builder.build(spec.guesses)
+        c_path, so_path = os.path.join(tmp, f"{name}.c"), os.path.join(tmp, f"{name}.so")
+        comp = compiler.Compiler(model, output_path=c_path, silent=True, **spec.compiler_kwargs)
+        with contextlib.redirect_stdout(open(os.devnull, "w")):
+            comp._generate_c_file()
+        subprocess.run(["gcc", "-o", so_path, c_path, *REFERENCE_FLAGS], check=True)
+        rng = np.random.default_rng(20250216 + len(name))
+        x0a, x0b, x1a, x1b = spec.extent
+        inside = np.stack([rng.uniform(x0a, x0b, 64), rng.uniform(x1a, x1b, 64)], axis=1)
+        unit = rng.uniform(-1.0, 1.0, (100, 2))
+        p_rand = rng.uniform(-10.0, 10.0, len(spec.args))
+        out[f"{name}_args"] = np.asarray(spec.args, dtype=np.float64)
+        out[f"{name}_inside_x"] = inside
+        out[f"{name}_inside_basis"] = basis_on_points(so_path, spec.args, inside)
+        out[f"{name}_unit_x"] = unit
+        out[f"{name}_unit_p"] = p_rand
+        out[f"{name}_unit_basis"] = basis_on_points(so_path, p_rand, unit)
+        out[f"{name}_unit_basis_args"] = basis_on_points(so_path, spec.args, unit)
+        print(f"   {name}: inside-extent norms {np.nanmin(out[f'{name}_inside_basis'][:, 0]):.6f}..{np.nanmax(out[f'{name}_inside_basis'][:, 0]):.6f}", flush=True)
+    np.savez_compressed(os.path.join(HERE, "basis.npz"), **out)
+    print("wrote basis.npz")
+
+
 if __name__ == "__main__":
-    main(sys.argv[1:] or list(GRIDS))
+    if "--basis" in sys.argv[1:]:
+        basis_goldens([a for a in sys.argv[1:] if a != "--basis"] or list(GRIDS))
+    else:
+        main(sys.argv[1:] or list(GRIDS))

@@ -75,6 +75,11 @@ void twin_grid(int op, const double* p, const double* ss, size_t N0, size_t N1, 
   }
 }
 
+// out: (n, 7) -- the records of the device kernel inflx_basis_points
+void twin_basis(const double* p, const double* pts, size_t n, double* out) {
+  for (size_t k = 0; k < n; ++k) inflx_basis_point(pts[2 * k], pts[2 * k + 1], p, out + 7 * k);
+}
+
 // out: (n, K)
 void twin_trajectory(int op, const double* p, const double* pts, size_t n, double* out) {
   const int K = width(op);

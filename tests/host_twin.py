@@ -34,6 +34,7 @@ class HostTwin:
         self.lib.twin_grid.argtypes = [C.c_int, _DP, _DP, C.c_size_t, C.c_size_t, _DP]
         self.lib.twin_trajectory.argtypes = [C.c_int, _DP, _DP, C.c_size_t, _DP]
         self.lib.twin_set_accuracy.argtypes = [C.c_double]
+        self.lib.twin_basis.argtypes = [_DP, _DP, C.c_size_t, _DP]
         self.n_parameters = self.lib.twin_n_parameters()
         self.out_mask = self.lib.twin_out_mask()
 
@@ -59,3 +60,10 @@ class HostTwin:
         out = np.zeros((pts.shape[0], k))
         self.lib.twin_trajectory(op, p.ctypes.data_as(_DP), pts.ctypes.data_as(_DP), pts.shape[0], out.ctypes.data_as(_DP))
         return out if k > 1 else out[..., 0]
+
+    def basis(self, p, pts):
+        p = np.ascontiguousarray(p, dtype=np.float64)
+        pts = np.ascontiguousarray(pts, dtype=np.float64)
+        out = np.zeros((pts.shape[0], 7))
+        self.lib.twin_basis(p.ctypes.data_as(_DP), pts.ctypes.data_as(_DP), pts.shape[0], out.ctypes.data_as(_DP))
+        return out

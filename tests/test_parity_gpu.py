@@ -403,3 +403,116 @@ def test_fused_summary_equals_numpy_over_the_arrays(name, gpu_lib):
     part = lib.sweep_stats(spec.args, spec.extent, n0, n1, row_begin=100, row_count=57)
     want = numpy_summary(lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1, row_begin=100, row_count=57))
     assert np.array_equal(part["count"], want["count"]) and np.array_equal(part["min"], want["min"]) and np.array_equal(part["max"], want["max"])
+
+
+# ---- basis validation (reference src/lib.rs:141-300) -------------------------------
+def _basis_goldens():
+    import os
+
+    from conftest import GOLDEN_DIR
+
+    return dict(np.load(os.path.join(GOLDEN_DIR, "basis.npz")))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_basis_on_points_matches_goldens(name, gpu_lib):
+    """v, w1 and their inner products from the device kernel against the reference's C functions."""
+    spec, art, lib = devlib(name, gpu_lib)
+    b = _basis_goldens()
+    for xk, pk, bk in (("inside_x", None, "inside_basis"), ("unit_x", "unit_p", "unit_basis"), ("unit_x", None, "unit_basis_args")):
+        p = b[f"{name}_{pk}"] if pk else b[f"{name}_args"]
+        x, want = b[f"{name}_{xk}"], b[f"{name}_{bk}"]
+        got = lib.basis_on_points(p, x)
+        tol.basis_close(got, want, f"{name}/{bk}", tol.basis_sensitivity(name, p, x, want))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_validate_basis_at_random_accepts_the_example_models(name, gpu_lib, capfd):
+    """What open_inflx_dylib(check_basis=True) runs (lib.rs:109-114): no exception for sound models;
+    points outside a model's domain only produce the reference's warnings."""
+    spec, art, lib = devlib(name, gpu_lib)
+    for seed in (1, 2, 3):
+        lib.validate_basis_at_random(seed)
+    err = capfd.readouterr().err
+    from inflatox_amd import _native
+
+    opened = _native.open_inflx_dylib(art.shared_object_path, True)  # seeds itself from the OS, like the reference
+    assert opened.n_fields == 2
+    capfd.readouterr()
+    if name in ("hyperbolic", "doc"):
+        assert "unable to verify" not in err
+
+
+def _defective(kind):
+    """The README hyperbolic model with its second basis vector spoiled after the symbolic stage."""
+    import copy
+
+    from inflatox_amd import Compiler, workloads
+
+    model = copy.copy(workloads.model_for("hyperbolic"))
+    v, w = [list(vec) for vec in model.basis]
+    if kind == "norm":
+        w = [c * 1.01 for c in w]  # |w1|^2 = 1.0201
+    else:
+        w = [a + 0.02 * b for a, b in zip(w, v)]  # v.w1 = 0.02
+    model.basis = [v, w]
+    return Compiler(model, silent=True).compile()
+
+
+@pytest.mark.parametrize("kind", ["norm", "oth"])
+def test_validate_basis_rejects_a_defective_basis(kind, gpu_lib):
+    from inflatox_amd import _native
+    from inflatox_amd.consistency_conditions import GeneralisedAL, InflationCondition
+
+    art = _defective(kind)
+    lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    with pytest.raises(_native.InflatoxBasisError) as e:
+        lib.validate_basis_at_random(5)
+    msg = str(e.value)
+    if kind == "norm":
+        assert msg.startswith("Expected basis vector 1 to be normalised everywhere in the models domain. Instead, found norm 1.02")
+    else:
+        assert msg.startswith("Expected basis vectors w0 and w1 to be orthogonal everywhere in the model's domain. Instead, found inner product")
+    # the same verdict from the oracle's restatement on the device's own numbers
+    x = np.random.default_rng(0).uniform(-1, 1, (50, 2))
+    p = np.array([1.0, 1.0, 1.0])
+    with pytest.raises(oracle.cpu_oracle.BasisDefect) as d:
+        oracle.cpu_oracle.check_basis(lib.basis_on_points(p, x), x, 1e-3)
+    assert d.value.kind == kind
+    # the constructor validates (reference consistency_conditions.py:38,50), and can be told not to
+    with pytest.raises(Exception):
+        GeneralisedAL(art)
+    cond = InflationCondition(art, validate_basis=False)
+    assert np.isfinite(cond.calc_V(np.array([0.5, 0.5]), p))
+    with pytest.raises(_native.InflatoxBasisError):
+        cond.validate_basis_on_domain(p, [0.1, 0.1], [1.0, 1.0], N=[8, 8])
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_validate_basis_on_domain_agrees_with_the_oracle(name, gpu_lib, capfd):
+    from inflatox_amd.consistency_conditions import InflationCondition
+
+    spec, art, lib = devlib(name, gpu_lib)
+    om, _ = oracle_model(name)
+    x0a, x0b, x1a, x1b = spec.extent
+    ss = [[x0a, x0b], [x1a, x1b]]
+    n = [16, 12]
+    want = None
+    try:
+        for pts in oracle.cpu_oracle.domain_points(n, ss):
+            oracle.cpu_oracle.check_basis(oracle.cpu_oracle.basis_on_points(om.path, spec.args, pts), pts, 1e-3)
+    except oracle.cpu_oracle.BasisDefect as d:
+        want = d.kind
+    cond = InflationCondition(art, validate_basis=False)
+    got = None
+    try:
+        cond.validate_basis_on_domain(spec.args, [x0a, x1a], [x0b, x1b], N=n)
+    except Exception as e:  # noqa: BLE001 - the reference raises a plain Exception
+        got = "norm" if "normalised" in str(e) else "oth"
+    capfd.readouterr()
+    assert got == want, (name, got, want)
+    # wrong number of axes / parameters are shape errors (lib.rs:223-245)
+    with pytest.raises(Exception):
+        lib.validate_basis_on_domain([4], spec.args, [[x0a, x0b]], 1e-3)
+    with pytest.raises(Exception):
+        lib.validate_basis_on_domain(n, list(spec.args) + [1.0], ss, 1e-3)

@@ -153,3 +153,40 @@ def check(got, ref, allowed, flaky=None, what=""):
     worst = float(ratio.max())
     assert worst <= 1.0, f"{what}: |gpu-ref| exceeds the allowance by x{worst:.3g} ({int((ratio > 1).sum())} of {ratio.size} points)"
     return worst
+
+
+# ---- basis validation (tests/test_basis.py, tests/test_parity_gpu.py) --------------------------------
+def basis_sensitivity(name, p, pts, want):
+    """How much the reference's own numbers move when the point moves by a few ulps: the measure of its
+    rounding error at ill-conditioned points (the angular model's basis cancels to ~1e-6 there)."""
+    from conftest import oracle_model
+    from oracle import cpu_oracle
+
+    om, _ = oracle_model(name)
+    rng = np.random.default_rng(11)
+    spread = np.zeros_like(want)
+    for _ in range(8):
+        moved = pts.copy()
+        for _ in range(int(rng.integers(1, 4))):
+            moved = np.nextafter(moved, np.where(rng.random(moved.shape) < 0.5, -np.inf, np.inf))
+        with np.errstate(invalid="ignore"):
+            d = np.abs(cpu_oracle.basis_on_points(om.path, p, moved) - want)
+        spread = np.fmax(spread, np.where(np.isfinite(d), d, 0.0))
+    return spread
+
+
+def basis_close(got, want, what, spread=None):
+    """Same NaN/Inf pattern; finite values within 1e-9 of the scale of their record (the validation
+    compares inner products with 1e-3) plus 64x the reference's own few-ulp sensitivity."""
+    assert np.array_equal(np.isnan(got), np.isnan(want)), f"{what}: NaN pattern"
+    inf = np.isinf(want)
+    assert np.array_equal(got[inf], want[inf]), f"{what}: Inf pattern"
+    fin = np.isfinite(want)
+    scale = np.ones_like(want)
+    vec = np.where(np.isfinite(want[:, 3:]), np.abs(want[:, 3:]), 0.0)
+    scale[:, 3:] = np.maximum(1.0, vec.max(axis=1, keepdims=True))
+    ip = np.where(np.isfinite(want[:, :3]), np.abs(want[:, :3]), 0.0)
+    scale[:, :3] = np.maximum(1.0, ip)
+    allow = 1e-9 * scale + (64.0 * spread if spread is not None else 0.0)
+    excess = np.abs(got[fin] - want[fin]) - allow[fin]
+    assert excess.size == 0 or excess.max() <= 0, f"{what}: error exceeds the allowance by {excess.max():.3e}"
