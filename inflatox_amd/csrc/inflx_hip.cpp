@@ -785,7 +785,12 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   };
   std::future<void> ready = std::async(std::launch::async, touch, pieces[0]);
   bool used[2] = {false, false};
-  auto drain = [&] { if (ready.valid()) ready.wait(); };
+  // on every exit -- errors included -- nothing may still be writing to the caller's buffer
+  auto drain = [&] {
+    if (ready.valid()) ready.wait();
+    (void)hipStreamSynchronize(m->stream);
+    (void)hipStreamSynchronize(m->copy_stream);
+  };
   for (size_t c = 0; c < pieces.size(); ++c) {
     const Piece& pc = pieces[c];
     const int b = (int)(c & 1);
@@ -813,7 +818,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     if (e != hipSuccess) { drain(); return fail(INFLX_ERR_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(e)); }
     used[b] = true;
   }
-  drain();
+  if (ready.valid()) ready.wait();
   HIP_TRY(hipStreamSynchronize(m->copy_stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return INFLX_OK;

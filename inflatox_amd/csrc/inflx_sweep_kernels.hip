@@ -284,11 +284,18 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + wave_col0) * 6;
       const inflx_d2* units = reinterpret_cast<const inflx_d2*>(tb);
+      // all three LDS reads are issued before the first (predicated) store: one LDS round trip per row
+      // instead of three (left alone, the compiler sinks every read into its store's branch)
+      inflx_d2 v[3];
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        v[s] = units[s * kWave + lane];
+        asm volatile("" : "+v"(v[s]));
+      }
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const unsigned q = s * kWave + lane;
-        const inflx_d2 v = units[q];
-        if (q < wave_units) store_d2(dst + 2 * q, v);
+        if (q < wave_units) store_d2(dst + 2 * q, v[s]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();

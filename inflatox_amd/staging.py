@@ -128,6 +128,11 @@ class HIPInflatoxPrinter(C99CodePrinter):
             if 3 <= abs(n) <= 2 * self.MAX_INT_POW:
                 body = f"inflx_hpow<{abs(n)}>({self._print(base)})"
                 return body if n > 0 else f"(1.0/{body})"
+            if n == -1:
+                # a stand-alone x**(-1/2) (inside a product sympy prints 1/sqrt(x) itself; on its own --
+                # e.g. as a cse definition -- C99 gets pow(x, -1.0/2.0), compiler.py:403-408): one sqrt and
+                # one division instead of the general pow; `+ 0.0` keeps pow's +inf at x = -0.0
+                return f"(1.0/sqrt({self._print(base)} + 0.0))"
         return super()._print_Pow(expr)
 
     def _operand(self, item, level):
