@@ -98,7 +98,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--model", default="hyperbolic")
-    ap.add_argument("--n", type=int, default=8192, help="grid points per axis")
+    ap.add_argument("--grid", dest="n", type=int, default=8192, help="grid points per axis")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     opt = ap.parse_args()
 
@@ -112,6 +112,14 @@ def main():
         raise SystemExit(f"--gpus {opt.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {opt.gpus}")
     # INFLX_BENCH_FORCE_DIST=1 exercises the process-group path (init, barrier, MAX) with a single rank
     distributed = world > 1 or os.environ.get("INFLX_BENCH_FORCE_DIST") == "1"
+    # Rehearsal knob for a one-GPU box: INFLX_BENCH_REHEARSE=1 lets several ranks share the visible GPUs
+    # (rank -> device local_rank % count) and synchronise over gloo, because RCCL refuses two ranks on one
+    # device.  Everything else -- sharding plan, per-rank sweeps, barrier, MAX over ranks -- is the real path.
+    rehearse = os.environ.get("INFLX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local_rank %= max(1, torch.cuda.device_count())
+    backend = "gloo" if rehearse else "nccl"
+    comm_device = "cpu" if rehearse else f"cuda:{local_rank}"
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
@@ -123,7 +131,10 @@ def main():
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            if rehearse:
+                dist.init_process_group(backend)
+            else:
+                dist.init_process_group(backend, device_id=torch.device("cuda", local_rank))
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -167,7 +178,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -189,7 +200,7 @@ def main():
         if distributed:
             from inflatox_amd.distributed import all_reduce_summary
 
-            local = all_reduce_summary(local, device=f"cuda:{local_rank}")
+            local = all_reduce_summary(local, device=comm_device)
         stats_info = {
             "ms": (time.perf_counter() - t0) * 1e3,
             "nanmax": [None if not np.isfinite(v) else float(v) for v in local["max"]],
@@ -216,7 +227,7 @@ def main():
             "config": {
                 "workload": f"{opt.model} model, {N0}x{N1} field grid, args {spec.args.tolist()}, extent {list(spec.extent)}, complete_analysis (6 f64/point, AoS), device-resident result",
                 "parameter_rows_per_gpu": 1,
-                "parallelism": f"parameter-axis x{world}" if world > 1 else "single GPU",
+                "parallelism": (f"parameter-axis x{world}" if world > 1 else "single GPU") + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearse else ""),
             },
             "roofline": {
                 "bound": "hbm",

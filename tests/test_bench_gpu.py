@@ -1,0 +1,50 @@
+"""bench.py contract on a GPU box: the one-line JSON of the N=1 run and a two-rank rehearsal of the
+N>1 path (ranks share the GPU and synchronise over gloo -- RCCL refuses two ranks per device)."""
+
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REQUIRED = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline")
+
+
+def _line(proc):
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    lines = [ln for ln in proc.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}"
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line():
+    proc = subprocess.run(
+        [sys.executable, "bench.py", "--grid", "2048", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600
+    )
+    line = _line(proc)
+    for key in REQUIRED:
+        assert key in line, key
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["warmup"] == 2
+    assert line["unit"] == "grid-points/s" and line["dtype"] == "f64" and line["scaling"] == "weak"
+    assert line["value"] > 1e9  # north_star's floor, on a grid 16x smaller than the headline one
+    roof = line["roofline"]
+    assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
+    assert "workload" in line["config"] and "model" not in line["config"]
+
+
+def test_two_rank_rehearsal():
+    env = dict(os.environ, INFLX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29533",
+           "bench.py", "--gpus", "2", "--grid", "2048", "--steps", "5", "--warmup", "2"]  # fmt: skip
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    line = _line(proc)
+    assert line["n_gpus"] == 2 and "cpu_baseline" not in line
+    assert "REHEARSAL" in line["config"]["parallelism"]
+    # both ranks' rows are counted: value = 2 * points * steps / max-over-ranks time
+    assert abs(line["value"] - 2 * 2048 * 2048 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-9
+    # the summary of the two parameter rows was combined across ranks (epsilon_V is finite everywhere)
+    assert line["summary_sweep"]["non_nan"][1] == 2 * 2048 * 2048
