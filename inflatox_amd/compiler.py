@@ -113,6 +113,58 @@ class CInflatoxPrinter(C99CodePrinter):
         return None
 
 
+class GSLInflatoxPrinter(CInflatoxPrinter):
+    """Prints sympy's Bessel and hypergeometric functions the way the reference's GSL printer does
+    (compiler.py:123-212): ``gsl_sf_bessel_J0(x[0])``, ``gsl_sf_hyperg_2F1(a, b, c, x)``, ...  Used to
+    number parameters in the reference's print order and by the oracle's C emitter; device code is printed
+    by :class:`inflatox_amd.staging.HIPInflatoxPrinter` (``inflx_sf_bessel_*``, csrc/inflx_sf.h)."""
+
+    HYPERH = "gsl_sf_hyperg"
+    BESSELH = "gsl_sf_bessel"
+    # sympy class name -> (GSL letter, orders with a function of their own, name for other integer
+    # orders, name for real orders or None)
+    _FAMILIES = {
+        "besselj": ("J", ("0", "1"), "Jn", "Jnu"),
+        "bessely": ("Y", ("0", "1"), "Yn", "Ynu"),
+        "besseli": ("I", ("0", "1"), "In", "Inu"),
+        "besselk": ("K", ("0", "1"), "Kn", "Knu"),
+        "jn": ("j", ("0", "1", "2"), "jl", None),
+        "yn": ("y", ("0", "1", "2"), "yl", None),
+    }
+    _HYPER = {(2, 0): "2F0", (2, 1): "2F1", (1, 1): "1F1", (0, 1): "0F1"}
+
+    def __init__(self, coordinate_symbols, coordinate_derivative_symbols, settings=None):
+        super().__init__(coordinate_symbols, coordinate_derivative_symbols, settings)
+        self.required_headers = []
+
+    def update_preamble(self, header):
+        if header not in self.required_headers:
+            self.required_headers.append(header)
+
+    def _bessel(self, expr):
+        letter, own, integer_name, real_name = self._FAMILIES[expr.func.__name__]
+        self.update_preamble(self.BESSELH)
+        nu, x = expr.args[0], self._print_Symbol(expr.args[1])  # the reference prints the argument as a symbol
+        if nu.is_integer:
+            n = int(float(self._print_Symbol(nu)))
+            if str(n) in own:
+                return f"gsl_sf_bessel_{letter}{n}({x})"
+            return f"gsl_sf_bessel_{integer_name}({n}, {x})"
+        if real_name is None:
+            raise KeyError("No non-integer impl found.")
+        return f"gsl_sf_bessel_{real_name}({self._print_Symbol(nu)}, {x})"
+
+    _print_besselj = _print_bessely = _print_besseli = _print_besselk = _print_jn = _print_yn = _bessel
+
+    def _print_hyper(self, expr):
+        self.update_preamble(self.HYPERH)
+        ap, bq, x = expr.args[0], expr.args[1], self.doprint(expr.args[2])
+        kind = self._HYPER.get((len(ap), len(bq)))
+        if kind is None:
+            raise Exception("Cannot compute hypergeometric functions other than 2F0, 2F1, 1F1 and 0F1")
+        return f"gsl_sf_hyperg_{kind}(" + ", ".join([self.doprint(a) for a in list(ap) + list(bq)] + [x]) + ")"
+
+
 # ---------------------------------------------------------------------------------------------
 # artefact + compiler front-end
 # ---------------------------------------------------------------------------------------------
@@ -184,6 +236,12 @@ class Compiler:
       from the reference where a model cancels catastrophically);
     * ``exact_constants`` (default False): full-precision pi, e, ... instead of the reference's
       12-digit fallback constants.
+
+    ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
+    (compiler.py:123-212).  Here nothing is linked: Bessel functions of integer order are device functions
+    of this package (csrc/inflx_sf.h) and print with or without the flag, which only sets the artefact's
+    ``USE_GSL`` global; Bessel functions of real order and hypergeometric functions raise
+    ``NotImplementedError`` while the code is generated.
     """
 
     c_prefix = "inflx_auto_"
@@ -223,8 +281,9 @@ class Compiler:
         exact_constants: bool = False,
         regroup: bool = False,
     ):
-        if link_gsl:
-            raise NotImplementedError("GSL special functions have no device implementation; link_gsl is not supported by the HIP back-end")
+        # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
+        # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
+        self.gsl = bool(link_gsl)
         if model.dim != 2:
             raise Exception("the HIP sweep back-end supports two-field models only")
         self.symbolic_out = model
@@ -269,7 +328,7 @@ class Compiler:
     def _number_parameters(self):
         """Reproduce compiler.py:474-539's print order far enough to number every parameter."""
         m = self.symbolic_out
-        pr = CInflatoxPrinter(m.coordinates, m.coordinate_tangents)
+        pr = (GSLInflatoxPrinter if self.gsl else CInflatoxPrinter)(m.coordinates, m.coordinate_tangents)
         plain = C99CodePrinter()._print_Symbol
         coords = set(m.coordinates) | set(m.coordinate_tangents)
 
@@ -334,13 +393,15 @@ class Compiler:
 
     def _hipcc_compile(self, header_text: str):
         kernel_src = os.path.join(_CSRC, "inflx_sweep_kernels.hip")
-        deps = [kernel_src, os.path.join(_CSRC, "inflx_ops.h"), os.path.join(_CSRC, "inflx_device_math.h"), os.path.join(_CSRC, "inflx_kernel_abi.h")]
+        deps = [kernel_src] + [os.path.join(_CSRC, f) for f in ("inflx_ops.h", "inflx_device_math.h", "inflx_kernel_abi.h", "inflx_sf.h", "inflx_sf_tables.h")]
         h = hashlib.sha256()
         h.update(header_text.encode())
         for d in deps:
             with open(d, "rb") as fh:
                 h.update(fh.read())
         opts = list(self.hipcc_opts)
+        if self.gsl:
+            opts.append("-DINFLX_USE_GSL=1")
         # the tile kernels keep TILE_ROWS x n_row doubles of row-stage values in LDS: shrink the tile for
         # models with very many row values so that it stays within ~64 KiB (two workgroups per CU)
         n_row = max(1, (self.stage_info or {}).get("nr", 1))

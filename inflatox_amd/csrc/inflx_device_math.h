@@ -47,3 +47,6 @@ INFLX_FN double inflx_csch(double x) { return 1.0 / sinh(x); }
 INFLX_FN double inflx_cot(double x) { return 1.0 / tan(x); }
 INFLX_FN double inflx_sec(double x) { return 1.0 / cos(x); }
 INFLX_FN double inflx_csc(double x) { return 1.0 / sin(x); }
+
+// Bessel functions (the reference's GSL path)
+#include "inflx_sf.h"

@@ -81,7 +81,10 @@ INFLX_EXPORT uint16_t VERSION[3] = {5, 0, 0};
 INFLX_EXPORT uint32_t DIM = INFLX_DIM;
 INFLX_EXPORT uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
 INFLX_EXPORT char MODEL_NAME[] = INFLX_MODEL_NAME;
-INFLX_EXPORT char USE_GSL = 0;
+#ifndef INFLX_USE_GSL
+#define INFLX_USE_GSL 0
+#endif
+INFLX_EXPORT char USE_GSL = INFLX_USE_GSL;  // Compiler(link_gsl=True): special functions come from inflx_sf.h
 INFLX_EXPORT InflxKernelInfo INFLX_KERNEL_INFO = {
     INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK,
     kThreads, 0};

@@ -189,3 +189,29 @@ ALL = {"hyperbolic": hyperbolic, "doc": doc, "angular": angular, "egno": egno, "
 
 def get(name: str) -> ModelSpec:
     return ALL[name]()
+
+
+# ---- models with special functions (the reference's GSL path, compiler.py:123-212) --------------------
+BESSEL_PROBE_FUNCTIONS = (
+    ("J", 0), ("J", 1), ("J", 5), ("Y", 0), ("Y", 1), ("Y", 3), ("I", 0), ("I", 1), ("I", 4), ("K", 0), ("K", 1), ("K", 2),
+    ("j", 0), ("j", 1), ("j", 2), ("j", 6), ("y", 0), ("y", 1), ("y", 2), ("y", 4),
+)  # fmt: skip
+
+
+def bessel_probe():
+    """V = sum_k c_k f_k(phi) over one function of every Bessel family and order class; a one-hot parameter
+    vector turns ``calc_V`` into a probe of a single device function (tests only)."""
+    phi, theta = sp.symbols("phi theta")
+    fn = {"J": sp.besselj, "Y": sp.bessely, "I": sp.besseli, "K": sp.besselk, "j": sp.jn, "y": sp.yn}
+    cs = sp.symbols(f"c0:{len(BESSEL_PROBE_FUNCTIONS)}")
+    potential = sum(c * fn[kind](order, phi) for c, (kind, order) in zip(cs, BESSEL_PROBE_FUNCTIONS))
+    return [phi, theta], [[1, 0], [0, 1]], potential
+
+
+def bessel_toy():
+    """A two-field model whose potential contains J0 (derivatives bring in J1, J2) -- the smallest model
+    that needs ``Compiler(link_gsl=True)`` in the reference."""
+    phi, theta = sp.symbols("phi theta")
+    m, L = sp.symbols("m L")
+    potential = m**2 * (2 + sp.besselj(0, phi)) * (1 + sp.Rational(1, 10) * sp.cos(theta))
+    return [phi, theta], [[1, 0], [0, L**2 * (1 + phi**2)]], potential

@@ -135,6 +135,42 @@ class HIPInflatoxPrinter(C99CodePrinter):
                 return f"(1.0/sqrt({self._print(base)} + 0.0))"
         return super()._print_Pow(expr)
 
+    # -- special functions (reference: GSLInflatoxPrinter, compiler.py:123-212 -> gsl_sf_bessel_*) ------
+    # device counterparts live in csrc/inflx_sf.h; integer orders only
+    _CYLINDRICAL = {"besselj": "J", "bessely": "Y", "besseli": "I", "besselk": "K"}
+    _SPHERICAL = {"jn": "j", "yn": "y"}
+
+    def _bessel(self, expr, letter, named_orders, general):
+        nu, arg = expr.args
+        if not (nu.is_number and nu.is_integer):
+            raise NotImplementedError(f"{expr.func.__name__} of non-integer or symbolic order {nu} has no device implementation (integer orders only)")
+        n = int(nu)
+        x = self._print(arg)
+        if n in named_orders:
+            return f"inflx_sf_bessel_{letter}{n}({x})"
+        return f"inflx_sf_bessel_{letter}{general}({n}, {x})"
+
+    def _print_besselj(self, expr):
+        return self._bessel(expr, "J", (0, 1), "n")
+
+    def _print_bessely(self, expr):
+        return self._bessel(expr, "Y", (0, 1), "n")
+
+    def _print_besseli(self, expr):
+        return self._bessel(expr, "I", (0, 1), "n")
+
+    def _print_besselk(self, expr):
+        return self._bessel(expr, "K", (0, 1), "n")
+
+    def _print_jn(self, expr):
+        return self._bessel(expr, "j", (0, 1, 2), "l")
+
+    def _print_yn(self, expr):
+        return self._bessel(expr, "y", (0, 1, 2), "l")
+
+    def _print_hyper(self, expr):
+        raise NotImplementedError("hypergeometric functions (gsl_sf_hyperg_* in the reference) have no device implementation")
+
     def _operand(self, item, level):
         """``parenthesize`` for an operand that may have been replaced by a stage variable."""
         text = self._print(item)

@@ -8,7 +8,9 @@ Pieces:
   * ``model_c.py``      restatement of the reference transpiler's C back-end: emits the
                         per-model C file with the reference's ABI and builds it with gcc
                         using the reference's compiler flags.
-  * ``cpu_oracle.py``   ctypes bindings for the two above.
+  * ``cpu_oracle.py``   ctypes bindings for the two above (+ the basis-validation restatement).
+  * ``special.py``      mpmath / scipy.special stand-in for the reference's GSL special functions
+                        (GSL is absent from this image: that row is **parity unpinned**).
 
 Parity status: pinned by the reference's known-answer test (tests/test_doc.py:50-51) and by
 golden vectors produced from the reference's own Python stages (tests/golden/); the Rust

@@ -1,0 +1,20 @@
+// Host build of csrc/inflx_sf.h for the CPU test-suite -- TEST INFRASTRUCTURE (the product only uses the
+// header inside gfx950 code objects).
+#include <cmath>
+#define INFLX_FN static inline
+using std::cos;
+using std::exp;
+using std::fabs;
+using std::log;
+using std::sin;
+using std::sqrt;
+#include "inflx_sf.h"
+
+extern "C" {
+#define F1(name) \
+  void sf_##name(const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_bessel_##name(x[i]); }
+#define F2(name) \
+  void sf_##name(int order, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_bessel_##name(order, x[i]); }
+F1(J0) F1(J1) F1(Y0) F1(Y1) F1(I0) F1(I1) F1(K0) F1(K1) F1(j0) F1(j1) F1(j2) F1(y0) F1(y1) F1(y2)
+F2(Jn) F2(Yn) F2(In) F2(Kn) F2(jl) F2(yl)
+}

@@ -1,0 +1,164 @@
+"""Special functions (reference compiler.py:123-212 -> GSL): the device header
+csrc/inflx_sf.h built for the host against mpmath, the two printers, and a Bessel model end to end on
+the host twin against the scipy stand-in.  GSL itself is absent from this image (parity unpinned, see
+oracle/special.py)."""
+
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+import sympy
+
+from conftest import golden  # noqa: F401  (keeps the tests directory on sys.path)
+from host_twin import HostTwin
+from inflatox_amd import Compiler, InflationModelBuilder, example_models
+from inflatox_amd.compiler import CInflatoxPrinter, GSLInflatoxPrinter
+from oracle import special
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+DP = C.POINTER(C.c_double)
+
+
+@pytest.fixture(scope="module")
+def sf():
+    src = os.path.join(HERE, "sf_host.cpp")
+    csrc = os.path.join(ROOT, "inflatox_amd", "csrc")
+    h = hashlib.sha1()
+    for f in (src, os.path.join(csrc, "inflx_sf.h"), os.path.join(csrc, "inflx_sf_tables.h")):
+        h.update(open(f, "rb").read())
+    so = os.path.join(tempfile.gettempdir(), f"inflx_sf_host_{h.hexdigest()[:12]}.so")
+    if not os.path.exists(so):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", f"-I{csrc}", src, "-o", so + ".tmp"], check=True)
+        os.replace(so + ".tmp", so)
+    return C.CDLL(so)
+
+
+def call(lib, kind, order, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    named = (0, 1, 2) if kind in "jy" else (0, 1)
+    if order in named:
+        getattr(lib, f"sf_{kind}{order}")(x.ctypes.data_as(DP), x.size, out.ctypes.data_as(DP))
+    else:
+        getattr(lib, f"sf_{kind}{'l' if kind in 'jy' else 'n'}")(C.c_int(order), x.ctypes.data_as(DP), x.size, out.ctypes.data_as(DP))
+    return out
+
+
+def points():
+    rng = np.random.default_rng(7)
+    return np.concatenate([rng.uniform(0, 4, 25), rng.uniform(4, 60, 50), rng.uniform(60, 400, 15), 10.0 ** rng.uniform(-8, 0, 10), [2.0, 3.0, 4.0, 8.0, 2.404825557695773]])
+
+
+def bound(order, x):
+    """error budget in units of the local amplitude: 2e-15 plus what the recurrence adds per order, plus
+    the phase error a large argument carries (one ulp of x is an absolute phase error)"""
+    return (2e-15 + 2e-16 * order) * max(1.0, x / 10.0)
+
+
+@pytest.mark.parametrize("kind", ["J", "Y", "I", "K", "j", "y"])
+@pytest.mark.parametrize("order", [0, 1, 2, 3, 7, 20])
+def test_device_functions_on_host_against_mpmath(sf, kind, order):
+    x = points()
+    if kind in "IK":
+        x = x[x < 300]
+    got = call(sf, kind, order, x)
+    for xi, g in zip(x, got):
+        want = special.mp_bessel(kind, order, xi)
+        if abs(want) > 1e300 or abs(want) < 1e-300:
+            assert not np.isnan(g)
+            continue
+        err = abs(float(want - float(g)))
+        assert err <= bound(order, xi) * special.mp_amplitude(kind, order, xi), (kind, order, xi, g, float(want))
+
+
+def test_symmetries_domains_and_limits(sf):
+    x = np.array([0.7, 3.3, 12.5])
+    for n in (0, 1, 2, 5):
+        assert np.array_equal(call(sf, "J", n, -x), (-1) ** n * call(sf, "J", n, x))
+        assert np.array_equal(call(sf, "I", n, -x), (-1) ** n * call(sf, "I", n, x))
+    out = np.zeros(3)
+    for name, sign in (("Jn", -1.0), ("Yn", -1.0), ("In", 1.0), ("Kn", 1.0)):  # negative orders
+        getattr(sf, f"sf_{name}")(C.c_int(-3), x.ctypes.data_as(DP), 3, out.ctypes.data_as(DP))
+        assert np.array_equal(out, sign * call(sf, name[0], 3, x)), name
+    bad = np.array([0.0, -1.0, np.nan])
+    for kind in "YKy":  # GSL: domain error for x <= 0
+        for order in (0, 1, 2, 4):
+            assert np.isnan(call(sf, kind, order, bad)).all(), (kind, order)
+    assert np.isnan(call(sf, "j", 3, np.array([-1.0]))).all()
+    zero = np.array([0.0])
+    assert call(sf, "J", 0, zero)[0] == 1.0 and call(sf, "J", 4, zero)[0] == 0.0
+    assert call(sf, "I", 0, zero)[0] == 1.0 and call(sf, "I", 3, zero)[0] == 0.0
+    assert call(sf, "j", 0, zero)[0] == 1.0 and call(sf, "j", 1, zero)[0] == 0.0 and call(sf, "j", 5, zero)[0] == 0.0
+    assert np.isinf(call(sf, "I", 0, np.array([800.0]))[0]) and call(sf, "K", 2, np.array([800.0]))[0] == 0.0
+    assert abs(call(sf, "I", 0, np.array([712.0]))[0] / 2.4684110577627523e307 - 1) < 1e-13  # no premature overflow
+
+
+def test_gsl_printer_strings_match_the_reference():
+    """The strings of the reference's tests/test_compiler.py:56-84."""
+    x, y, a, b, xdot, ydot = sympy.symbols("x y a b \\dot{{x}} \\dot{{y}}")
+    pr = GSLInflatoxPrinter([x, y], [xdot, ydot])
+    pr.doprint(sympy.besselj(1, x))
+    assert pr.BESSELH in pr.required_headers
+    pr.doprint(sympy.hyper([], [1], x))
+    assert pr.HYPERH in pr.required_headers
+    assert pr.doprint(sympy.besselj(0, x)) == "gsl_sf_bessel_J0(x[0])"
+    assert pr.doprint(sympy.besselj(1, x)) == "gsl_sf_bessel_J1(x[0])"
+    assert pr.doprint(sympy.besselj(10, x)) == "gsl_sf_bessel_Jn(10, x[0])"
+    assert pr.doprint(sympy.besselj(0.5, x)) == "gsl_sf_bessel_Jnu(0.50000000000000000, x[0])"
+    assert pr.doprint(sympy.hyper([0, 1], [], x)) == "gsl_sf_hyperg_2F0(0, 1, x[0])"
+    assert pr.doprint(sympy.hyper([0, 1], [2], x)) == "gsl_sf_hyperg_2F1(0, 1, 2, x[0])"
+    assert pr.doprint(sympy.hyper([0], [1], x)) == "gsl_sf_hyperg_1F1(0, 1, x[0])"
+    assert pr.doprint(sympy.hyper([], [0], x)) == "gsl_sf_hyperg_0F1(0, x[0])"
+    with pytest.raises(Exception) as exc:
+        pr.doprint(sympy.hyper([0, 3, 4], [1, 2], x))
+    assert "Cannot compute" in str(exc.value)
+    # remaining families of compiler.py:199-212
+    assert pr.doprint(sympy.bessely(1, y)) == "gsl_sf_bessel_Y1(x[1])"
+    assert pr.doprint(sympy.besseli(3, x)) == "gsl_sf_bessel_In(3, x[0])"
+    assert pr.doprint(sympy.besselk(0, x)) == "gsl_sf_bessel_K0(x[0])"
+    assert pr.doprint(sympy.jn(2, x)) == "gsl_sf_bessel_j2(x[0])"
+    assert pr.doprint(sympy.yn(7, x)) == "gsl_sf_bessel_yl(7, x[0])"
+    assert isinstance(pr, CInflatoxPrinter) and pr.doprint(x**2 + y) == "pow(x[0], 2) + x[1]"
+
+
+def _toy():
+    fields, metric, potential = example_models.bessel_toy()
+    return InflationModelBuilder.new(fields, metric, potential, model_name="bessel_toy", init_sympy_printing=False, silent=True).build()
+
+
+def test_device_printer_and_unsupported_functions():
+    model = _toy()
+    comp = Compiler(model, silent=True, link_gsl=True)
+    hdr = comp._generate_hip_header()
+    assert "inflx_sf_bessel_J0(x0)" in hdr and "inflx_sf_bessel_J1(x0)" in hdr and "inflx_sf_bessel_Jn(2, x0)" in hdr
+    assert comp.symbol_dict == {"phi": "x[0]", "theta": "x[1]", "m": "args[0]", "L": "args[1]"}
+    # Bessel functions of x[0] alone are row-stage work: none may be left in the per-point stage
+    point_stage = hdr[hdr.index("inflx_stage_point") : hdr.index("inflx_basis_point")]
+    assert "inflx_sf_bessel" not in point_stage
+    phi, theta = model.coordinates
+    nu = sympy.Symbol("nu")
+    for bad in (sympy.besselj(sympy.Rational(1, 2), phi), sympy.besselj(nu, phi), sympy.hyper([1, 2], [3], phi)):
+        fields, metric, _ = example_models.bessel_toy()
+        m2 = InflationModelBuilder.new(fields, metric, bad + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
+        with pytest.raises(NotImplementedError):
+            Compiler(m2, silent=True, link_gsl=True)._generate_hip_header()
+
+
+def test_bessel_model_on_host_twin_against_scipy_stand_in():
+    model = _toy()
+    comp = Compiler(model, silent=True, link_gsl=True)
+    tw = HostTwin(comp._generate_hip_header())
+    args = np.array([1.3, 0.7])
+    n0, n1, ext = 24, 20, (0.3, 14.0, 0.1, 3.0)
+    got = tw.grid(4, args, ext, n0, n1).reshape(-1, 5)
+    import oracle
+
+    want = special.raw_values(model, comp.symbol_dict, args, oracle.grid_points(ext, n0, n1))
+    scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
+    assert np.isfinite(want).all()
+    assert (np.abs(got - want) / scale).max() < 1e-10

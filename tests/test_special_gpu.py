@@ -1,0 +1,65 @@
+"""Special functions on the GPU (reference: the GSL path, compiler.py:123-212): every device Bessel
+function probed through ``calc_V`` against mpmath, and a Bessel model swept against the scipy stand-in."""
+
+import numpy as np
+import pytest
+import tolerance as tol
+
+import oracle
+from oracle import special
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(factory, name, **kw):
+    from inflatox_amd import Compiler, InflationModelBuilder
+
+    fields, metric, potential = factory()
+    model = InflationModelBuilder.new(fields, metric, potential, model_name=name, init_sympy_printing=False, silent=True, **kw).build()
+    comp = Compiler(model, silent=True, link_gsl=True)
+    return model, comp, comp.compile()
+
+
+def test_every_device_bessel_function_against_mpmath(gpu_lib):
+    from inflatox_amd import example_models
+    from inflatox_amd.consistency_conditions import InflationCondition
+
+    model, comp, art = _build(example_models.bessel_probe, "bessel_probe", assertions=False, simplify=False)
+    cond = InflationCondition(art, validate_basis=False)
+    rng = np.random.default_rng(5)
+    xs = np.concatenate([rng.uniform(0.05, 4, 12), rng.uniform(4, 40, 20), [2.0, 3.0, 4.0, 8.0]])
+    pts = np.stack([xs, np.zeros_like(xs)], axis=1)
+    for k, (kind, order) in enumerate(example_models.BESSEL_PROBE_FUNCTIONS):
+        p = np.zeros(art.n_parameters)
+        p[int(art.symbol_dictionary[f"c{k}"][5:-1])] = 1.0
+        got = cond.dylib.sweep_on_trajectory(gpu_lib.OP_RAW, p, pts)[:, 0]
+        for xi, g in zip(xs, got):
+            want = special.mp_bessel(kind, order, xi)
+            budget = (2e-15 + 2e-16 * order) * max(1.0, xi / 10.0) * special.mp_amplitude(kind, order, xi)
+            assert abs(float(want - float(g))) <= budget, (kind, order, xi, g, float(want))
+
+
+def test_bessel_model_sweep_against_scipy_stand_in(gpu_lib):
+    from inflatox_amd import example_models
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    model, comp, art = _build(example_models.bessel_toy, "bessel_toy")
+    assert art.n_parameters == 2
+    al = GeneralisedAL(art)  # validates the basis at random points on the device
+    args = np.array([1.3, 0.7])
+    n0, n1, ext = 96, 80, (0.3, 14.0, 0.1, 3.0)
+    pts = oracle.grid_points(ext, n0, n1)
+    want = special.raw_values(model, comp.symbol_dict, args, pts)
+    raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), n0, n1).reshape(-1, 5)
+    scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
+    assert (np.abs(raw - want) / scale).max() < 1e-10
+    # the six quantities: numpy restatement of ops::complete_analysis applied to the stand-in's raw values
+    out = np.stack(al.complete_analysis(args, *ext, n0, n1, progress=False), axis=-1).reshape(-1, 6)
+    ref = tol.epilogue(want)
+    assert np.array_equal(np.isnan(out), np.isnan(ref))
+    fin = np.isfinite(ref)
+    # derived quantities amplify the raw differences near zeros of v10 / V: compare where well-conditioned
+    err = np.abs(out[fin] - ref[fin]) / np.maximum(np.abs(ref[fin]), 1e-6)
+    assert np.quantile(err, 0.99) < 1e-9 and err.max() < 1e-5
+    # USE_GSL is set in the artefact, as in the reference (compiler.py:560)
+    assert al.dylib is not None
