@@ -90,3 +90,53 @@ def test_two_gloo_ranks_shard_and_gather(case, tmp_path):
     mp.spawn(_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
     axes = {open(tmp_path / f"ok_{r}").read() for r in range(2)}
     assert axes == ({"param"} if case[1] >= 2 else {"rows"})
+
+
+# ---- the same two-rank exercise with the HIP sweep as the local compute step ---------------------------
+# (GPU box: both ranks use the one visible GPU and exchange CPU tensors over gloo, because RCCL refuses
+# two ranks per device; partition, per-rank launch through the C ABI, gather and summary are the product's)
+def _gpu_worker(rank, world, port, case, tmpdir):
+    import torch
+    import torch.distributed as dist
+
+    from inflatox_amd import _native, workloads
+    from inflatox_amd.distributed import HipCompute
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        name, P, N0, N1 = case
+        spec, art = workloads.artifact_for(name)
+        lib = _native.InflatoxDevLib(art.shared_object_path, device=0)
+        args = np.stack([spec.args * (1.0 + 0.1 * k) for k in range(P)])
+        hip = HipCompute(lib, spec.extent, N0, N1)
+
+        def compute(p_rows, row_begin, row_count):
+            block = hip(p_rows, row_begin, row_count)
+            torch.cuda.synchronize()
+            return block.cpu()
+
+        plan, full = ShardedSweep(compute, rank, world).run(args, N0, gather=True)
+        want = lib.sweep_host(_native.OP_COMPLETE, args, np.array(spec.extent).reshape(2, 2), N0, N1)
+        assert tuple(full.shape) == want.shape, (full.shape, want.shape)
+        assert np.array_equal(full.numpy(), want, equal_nan=True)
+        # summaries: every rank reduces its own block on the device, the ranks combine over the process group
+        if plan.axis == "param":
+            local = lib.sweep_stats(args[plan.p_begin : plan.p_begin + plan.p_count], spec.extent, N0, N1)
+            combined = all_reduce_summary(local)
+            whole = numpy_summary(want)
+            assert np.array_equal(combined["count"], whole["count"])
+            assert np.array_equal(combined["min"], whole["min"]) and np.array_equal(combined["max"], whole["max"])
+        open(os.path.join(tmpdir, f"ok_{rank}"), "w").write(plan.axis)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", [("hyperbolic", 3, 96, 80), ("doc", 1, 101, 72), ("d5", 2, 64, 64)], ids=["param-axis", "row-axis", "d5-param-axis"])
+def test_two_ranks_share_the_gpu_with_hip_compute(case, tmp_path):
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_gpu_worker, args=(2, port, case, str(tmp_path)), nprocs=2, join=True)
+    axes = {open(tmp_path / f"ok_{r}").read() for r in range(2)}
+    assert axes == ({"param"} if case[1] >= 2 else {"rows"})
