@@ -355,14 +355,19 @@ void warn(const char* fmt, ...) {
   va_end(ap);
 }
 
+// a float the way Rust's Display/Debug prints it: NaN, inf, -inf, otherwise `digits` decimals (or %g)
+std::string num_text(double v, int digits = -1) {
+  if (std::isnan(v)) return "NaN";
+  if (std::isinf(v)) return v > 0 ? "inf" : "-inf";
+  char buf[64];
+  if (digits >= 0) snprintf(buf, sizeof buf, "%.*f", digits, v); else snprintf(buf, sizeof buf, "%.17g", v);
+  return buf;
+}
+
 std::string list_text(const double* v, size_t n) {
   // Rust's {:.03?} of a Vec<f64>
   std::string s = "[";
-  char buf[64];
-  for (size_t k = 0; k < n; ++k) {
-    snprintf(buf, sizeof buf, "%s%.3f", k ? ", " : "", v[k]);
-    s += buf;
-  }
+  for (size_t k = 0; k < n; ++k) s += (k ? ", " : "") + num_text(v[k], 3);
   return s + "]";
 }
 
@@ -390,21 +395,21 @@ int check_basis(const double* basis, const double* x, size_t n, double accuracy,
       const std::string vi = list_text(b + 3 + 2 * i, 2), vj = list_text(b + 3 + 2 * j, 2);
       if (i == j) {
         if (!std::isnormal(ip)) {
-          warn("Norm of basisvector %d is %g at field-space point %s. v%d=%s\nAre we outside the model's domain?", i, ip,
-               point.c_str(), i, vi.c_str());
+          warn("Norm of basisvector %d is %s at field-space point %s. v%d=%s\nAre we outside the model's domain?", i,
+               num_text(ip).c_str(), point.c_str(), i, vi.c_str());
           encountered_nan = true;
         } else if (std::fabs(ip - 1.) >= accuracy) {
           return fail(INFLX_ERR_BASIS, "Expected basis vector %d to be normalised everywhere in the models domain. Instead, "
-                      "found norm %g at %s.", i, ip, point.c_str());
+                      "found norm %s at %s.", i, num_text(ip).c_str(), point.c_str());
         }
       } else {
         if (!std::isnormal(ip) && ip != 0.0) {
-          warn("w%d•w%d = %g at field-space point %s.\nv%d=%s\nv%d=%s\nAre we outside the model's domain?", i, j, ip,
-               point.c_str(), i, vi.c_str(), j, vj.c_str());
+          warn("w%d•w%d = %s at field-space point %s.\nv%d=%s\nv%d=%s\nAre we outside the model's domain?", i, j,
+               num_text(ip).c_str(), point.c_str(), i, vi.c_str(), j, vj.c_str());
           encountered_nan = true;
         } else if (std::fabs(ip) >= accuracy) {
           return fail(INFLX_ERR_BASIS, "Expected basis vectors w%d and w%d to be orthogonal everywhere in the model's domain. "
-                      "Instead, found inner product %g at %s.", i, j, ip, point.c_str());
+                      "Instead, found inner product %s at %s.", i, j, num_text(ip).c_str(), point.c_str());
         }
       }
     }
