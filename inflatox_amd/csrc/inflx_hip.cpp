@@ -78,7 +78,8 @@ unsigned prefault_threads() {
 // Make the pages of a host destination range resident before the DMA engine writes to them.
 // A result array fresh from np.zeros has no physical pages yet; letting the device-to-host copy fault
 // them in one by one runs at 14 GB/s, copying into resident pages at 50 GB/s (scripts/pinned_probe.py).
-// Contents are preserved (MADV_POPULATE_WRITE, or a read-modify-write of one byte per page).
+// Contents are preserved (a read-modify-write of one byte per page; MADV_POPULATE_WRITE on request -- on the
+// GPU box's host touching populates huge pages 2-5x faster, scripts/micro/prefault_probe.cpp).
 void prefault_range(char* begin, size_t bytes) {
   const size_t page = (size_t)sysconf(_SC_PAGESIZE);
   char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(begin) + page - 1) / page * page);
@@ -89,9 +90,13 @@ void prefault_range(char* begin, size_t bytes) {
 #endif
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), (size_t)(hi - lo) / (size_t(8) << 20) + 1);
+  static const bool use_populate = [] {
+    const char* e = getenv("INFLX_PREFAULT_MODE");  // tuning knob: "populate" or "touch"
+    return e && strcmp(e, "populate") == 0;
+  }();
   auto work = [page](char* a, char* b) {
 #ifdef MADV_POPULATE_WRITE
-    if (madvise(a, (size_t)(b - a), MADV_POPULATE_WRITE) == 0) return;
+    if (use_populate && madvise(a, (size_t)(b - a), MADV_POPULATE_WRITE) == 0) return;
 #endif
     for (volatile char* q = a; q < b; q += page) *q = *q;
   };
