@@ -66,6 +66,16 @@ size_t chunk_bytes_limit() {
   }();
   return v;
 }
+// host-result sweeps whose result is at most this large are evaluated into one device buffer and copied
+// back with a single device-to-host copy; larger ones go through the chunk pipeline
+size_t whole_result_limit() {
+  static const size_t v = [] {
+    const char* e = getenv("INFLX_WHOLE_RESULT_MB");  // tuning knob; 0 disables the path
+    const long mb = e ? atol(e) : -1;
+    return (size_t)(mb >= 0 ? mb : 8192) << 20;
+  }();
+  return v;
+}
 unsigned prefault_threads() {
   static const unsigned v = [] {
     const char* e = getenv("INFLX_PREFAULT_THREADS");  // tuning knob
@@ -73,6 +83,35 @@ unsigned prefault_threads() {
     return (unsigned)(n > 0 ? n : 8);
   }();
   return v;
+}
+
+// Write-fault every page of a range without changing it: an atomic OR of 0 into one byte per page.  The
+// atomic matters: helper threads may still be walking a buffer the DMA engine has started to fill, and a
+// plain read-then-write could put a stale byte back over a freshly copied one; a locked read-modify-write
+// holds the cache line for its duration, so a coherent DMA write lands entirely before or after it.
+void touch_range(char* begin, size_t bytes) {
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(begin) + page - 1) / page * page);
+  char* hi = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(begin + bytes) / page * page);
+#if defined(__x86_64__)
+  // spelled in assembly: compilers turn an idempotent atomic OR into a fenced *load*, which would map the
+  // shared zero page instead of allocating a writable one
+  for (char* q = lo; q < hi; q += page) asm volatile("lock orb $0, %0" : "+m"(*q) : : "cc");
+#else
+  if (hi > lo && madvise(lo, (size_t)(hi - lo), MADV_POPULATE_WRITE) != 0)
+    for (volatile char* q = lo; q < hi; q += page) *q = *q;  // last resort, only safe when nothing else writes
+#endif
+}
+
+void advise_huge_pages(char* begin, size_t bytes) {
+#ifdef MADV_HUGEPAGE
+  const size_t page = (size_t)sysconf(_SC_PAGESIZE);
+  char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(begin) + page - 1) / page * page);
+  char* hi = reinterpret_cast<char*>(reinterpret_cast<uintptr_t>(begin + bytes) / page * page);
+  if (hi > lo) (void)madvise(lo, (size_t)(hi - lo), MADV_HUGEPAGE);
+#else
+  (void)begin, (void)bytes;
+#endif
 }
 
 // Make the pages of a host destination range resident before the DMA engine writes to them.
@@ -94,11 +133,11 @@ void prefault_range(char* begin, size_t bytes) {
     const char* e = getenv("INFLX_PREFAULT_MODE");  // tuning knob: "populate" or "touch"
     return e && strcmp(e, "populate") == 0;
   }();
-  auto work = [page](char* a, char* b) {
+  auto work = [](char* a, char* b) {
 #ifdef MADV_POPULATE_WRITE
     if (use_populate && madvise(a, (size_t)(b - a), MADV_POPULATE_WRITE) == 0) return;
 #endif
-    for (volatile char* q = a; q < b; q += page) *q = *q;
+    touch_range(a, (size_t)(b - a));
   };
   std::vector<std::thread> pool;
   const size_t pages = (size_t)(hi - lo) / page;
@@ -145,6 +184,8 @@ struct inflx_model {
   hipStream_t params_stream = nullptr;   // stream the last upload was ordered on
   void* d_chunk[2] = {nullptr, nullptr};
   size_t d_chunk_cap[2] = {0, 0};
+  void* d_whole = nullptr;  // whole-result buffer of the host path (results up to whole_result_limit())
+  size_t d_whole_cap = 0;
   hipEvent_t chunk_done[2] = {nullptr, nullptr};
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t t0 = nullptr, t1 = nullptr;
@@ -572,6 +613,7 @@ void inflx_close(inflx_model* m) {
   if (m->t1) (void)hipEventDestroy(m->t1);
   if (m->d_params) (void)hipFree(m->d_params);
   if (m->d_stats) (void)hipFree(m->d_stats);
+  if (m->d_whole) (void)hipFree(m->d_whole);
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->side) (void)hipStreamDestroy(m->side);
   if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
@@ -772,6 +814,44 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
 
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
+  const size_t total = P * row_count * row_bytes;
+  if (total <= whole_result_limit() && P <= 65535) {
+    // One launch for everything, one copy for everything: the device buffer has the layout of `out`.
+    // The destination pages are made resident by helper threads that run ahead of the copy: the first
+    // stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the resident
+    // frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
+    if (total > m->d_whole_cap) {
+      if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
+      m->d_whole = nullptr;
+      m->d_whole_cap = 0;
+      HIP_TRY(hipMalloc(&m->d_whole, total));
+      m->d_whole_cap = total;
+    }
+    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
+    if (rc) return rc;
+    advise_huge_pages(out, total);
+    const size_t head = std::min<size_t>(total, size_t(64) << 20);
+    prefault_range(out, head);
+    std::vector<std::thread> pool;
+    if (total > head) {
+      const size_t stripe = size_t(16) << 20;
+      const size_t nstripes = (total - head + stripe - 1) / stripe;
+      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+      const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), nstripes);
+      for (unsigned t = 0; t < nthreads; ++t)
+        pool.emplace_back([=] {
+          for (size_t k = t; k < nstripes; k += nthreads) {
+            const size_t off = head + k * stripe;
+            touch_range(out + off, std::min(stripe, total - off));
+          }
+        });
+    }
+    hipError_t e = hipMemcpyAsync(out, m->d_whole, total, hipMemcpyDeviceToHost, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    for (auto& th : pool) th.join();
+    if (e != hipSuccess) return fail(INFLX_ERR_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(e));
+    return INFLX_OK;
+  }
   // rows per chunk: whole rows of ONE parameter row at a time (keeps every copy contiguous in the
   // AoS result; the SoA result is copied plane by plane)
   size_t rows_per_chunk = std::max<size_t>(1, chunk_bytes_limit() / row_bytes);

@@ -9,7 +9,7 @@ README hyperbolic model (the model north_star states the 1e-10 bar for) the plai
 import numpy as np
 import pytest
 import tolerance as tol
-from conftest import MODELS, compare, golden, oracle_model
+from conftest import MODELS, compare, generalised_al, golden, oracle_model
 
 import oracle
 from oracle import OP
@@ -254,7 +254,7 @@ def test_flag_quantum_dif(name, gpu_lib):
 
     spec, art, lib = devlib(name, gpu_lib)
     om, _ = oracle_model(name)
-    al = GeneralisedAL(art)
+    al = generalised_al(art)
     n0, n1 = 130, 333
     for accuracy in (1e-3, 0.5, 0.9):
         got = al.flag_quantum_dif(spec.args, *spec.extent, n0, n1, progress=False, accuracy=accuracy)
@@ -302,7 +302,7 @@ def test_reference_trajectory_fixtures(name, loader, gpu_lib):
         traj = np.loadtxt(os.path.join(d, "d5_trajectory.dat"))
     spec, art, lib = devlib(name, gpu_lib)
     om, _ = oracle_model(name)
-    al = GeneralisedAL(art)
+    al = generalised_al(art)
     six = al.complete_analysis_ot(spec.args, traj, progress=False)
     assert len(six) == 6 and all(a.shape == (traj.shape[0], 1) for a in six)  # np.split(out, 6, 1), like the reference
     got = np.concatenate(six, axis=1)
@@ -426,21 +426,72 @@ def test_basis_on_points_matches_goldens(name, gpu_lib):
         tol.basis_close(got, want, f"{name}/{bk}", tol.basis_sensitivity(name, p, x, want))
 
 
+def _splitmix_draws(seed, n_par, num_points=100):
+    """The parameter vector and points inflx_validate_basis_at_random(seed) draws (splitmix64, 53-bit
+    mantissa; csrc/inflx_hip.cpp unit_random)."""
+    mask = (1 << 64) - 1
+    state = seed
+
+    def unit():
+        nonlocal state
+        state = (state + 0x9E3779B97F4A7C15) & mask
+        z = state
+        z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & mask
+        z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & mask
+        z ^= z >> 31
+        return (z >> 11) * 2.0**-53
+
+    p = np.array([10.0 * (-1.0 + 2.0 * unit()) for _ in range(n_par)])
+    x = np.array([-1.0 + 2.0 * unit() for _ in range(2 * num_points)]).reshape(num_points, 2)
+    return p, x
+
+
 @pytest.mark.parametrize("name", MODELS)
-def test_validate_basis_at_random_accepts_the_example_models(name, gpu_lib, capfd):
-    """What open_inflx_dylib(check_basis=True) runs (lib.rs:109-114): no exception for sound models;
-    points outside a model's domain only produce the reference's warnings."""
-    spec, art, lib = devlib(name, gpu_lib)
-    for seed in (1, 2, 3):
-        lib.validate_basis_at_random(seed)
-    err = capfd.readouterr().err
+def test_validate_basis_at_random_gives_the_reference_verdict(name, gpu_lib, capfd):
+    """What open_inflx_dylib(check_basis=True) runs (lib.rs:109-114).  For every seed the device's verdict --
+    pass, or BasisNorm / BasisOth -- must be the one the oracle's restatement reaches on the reference's C
+    functions at the very same draws; points outside a model's domain only produce warnings.  (The
+    ill-conditioned angular model fails this check for ~7 % of the draws, in the reference as here.)"""
     from inflatox_amd import _native
 
-    opened = _native.open_inflx_dylib(art.shared_object_path, True)  # seeds itself from the OS, like the reference
-    assert opened.n_fields == 2
-    capfd.readouterr()
+    spec, art, lib = devlib(name, gpu_lib)
+    om, _ = oracle_model(name)
+    verdicts = []
+
+    def verdict(basis, pts):
+        try:
+            oracle.cpu_oracle.check_basis(basis, pts, 1e-3)
+            return None
+        except oracle.cpu_oracle.BasisDefect as d:
+            return d.kind
+
+    for seed in range(1, 41):
+        p, x = _splitmix_draws(seed, art.n_parameters)
+        try:
+            lib.validate_basis_at_random(seed)
+            got = None
+        except _native.InflatoxBasisError as e:
+            got = "norm" if "normalised" in str(e) else "oth"
+        verdicts.append(got)
+        # (1) the library's verdict is the reference's test sequence applied to the device's own numbers
+        dev = lib.basis_on_points(p, x)
+        assert got == verdict(dev, x), (name, seed)
+        # (2) on the reference's numbers the verdict is the same, leaving out points at which the reference's
+        #     own value moves by more than a tenth of the threshold when its input moves by a few ulps (there
+        #     both evaluations are noise at the level the check looks at)
+        ref = oracle.cpu_oracle.basis_on_points(om.path, p, x)
+        stable = 64.0 * tol.basis_sensitivity(name, p, x, ref)[:, :3].max(axis=1) < 1e-4
+        stable &= (np.isnan(dev[:, :3]) == np.isnan(ref[:, :3])).all(axis=1)
+        assert verdict(dev[stable], x[stable]) == verdict(ref[stable], x[stable]), (name, seed)
+    err = capfd.readouterr().err
+    if name in ("hyperbolic", "doc", "egno", "d5"):
+        assert verdicts == [None] * 40  # sound models pass; the angular model trips the check now and then
     if name in ("hyperbolic", "doc"):
         assert "unable to verify" not in err
+    # OS-seeded, as the constructor uses it
+    if name != "angular":
+        assert _native.open_inflx_dylib(art.shared_object_path, True).n_fields == 2
+    capfd.readouterr()
 
 
 def _defective(kind):

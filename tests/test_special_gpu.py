@@ -40,12 +40,13 @@ def test_every_device_bessel_function_against_mpmath(gpu_lib):
 
 
 def test_bessel_model_sweep_against_scipy_stand_in(gpu_lib):
+    from conftest import generalised_al
     from inflatox_amd import example_models
-    from inflatox_amd.consistency_conditions import GeneralisedAL
 
     model, comp, art = _build(example_models.bessel_toy, "bessel_toy")
     assert art.n_parameters == 2
-    al = GeneralisedAL(art)  # validates the basis at random points on the device
+    al = generalised_al(art)
+    al.dylib.validate_basis_at_random(11)  # the constructor's check, at fixed draws
     args = np.array([1.3, 0.7])
     n0, n1, ext = 96, 80, (0.3, 14.0, 0.1, 3.0)
     pts = oracle.grid_points(ext, n0, n1)
