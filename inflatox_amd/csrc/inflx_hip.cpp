@@ -72,7 +72,7 @@ size_t whole_result_limit() {
   static const size_t v = [] {
     const char* e = getenv("INFLX_WHOLE_RESULT_MB");  // tuning knob; 0 disables the path
     const long mb = e ? atol(e) : -1;
-    return (size_t)(mb >= 0 ? mb : 8192) << 20;
+    return (size_t)(mb >= 0 ? mb : 65536) << 20;
   }();
   return v;
 }
@@ -815,18 +815,24 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
   const size_t total = P * row_count * row_bytes;
-  if (total <= whole_result_limit() && P <= 65535) {
+  bool whole = total <= whole_result_limit() && P <= 65535;
+  if (whole && total > m->d_whole_cap) {
+    if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
+    m->d_whole = nullptr;
+    m->d_whole_cap = 0;
+    if (hipMalloc(&m->d_whole, total) == hipSuccess) {
+      m->d_whole_cap = total;
+    } else {
+      (void)hipGetLastError();  // not enough free HBM for the whole result: the chunk pipeline needs 64 MiB
+      m->d_whole = nullptr;
+      whole = false;
+    }
+  }
+  if (whole) {
     // One launch for everything, one copy for everything: the device buffer has the layout of `out`.
     // The destination pages are made resident by helper threads that run ahead of the copy: the first
     // stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the resident
     // frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
-    if (total > m->d_whole_cap) {
-      if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
-      m->d_whole = nullptr;
-      m->d_whole_cap = 0;
-      HIP_TRY(hipMalloc(&m->d_whole, total));
-      m->d_whole_cap = total;
-    }
     rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
     if (rc) return rc;
     advise_huge_pages(out, total);
@@ -849,6 +855,12 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     hipError_t e = hipMemcpyAsync(out, m->d_whole, total, hipMemcpyDeviceToHost, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     for (auto& th : pool) th.join();
+    // a buffer of many GiB is not kept between calls (the model would sit on that much HBM)
+    if (m->d_whole_cap > (size_t(4) << 30)) {
+      (void)hipFree(m->d_whole);
+      m->d_whole = nullptr;
+      m->d_whole_cap = 0;
+    }
     if (e != hipSuccess) return fail(INFLX_ERR_DEVICE, "device-to-host copy failed: %s", hipGetErrorString(e));
     return INFLX_OK;
   }
