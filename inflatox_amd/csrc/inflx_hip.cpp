@@ -144,7 +144,15 @@ void prefault_range(char* begin, size_t bytes) {
   for (unsigned t = 0; t < nthreads; ++t) {
     char* a = lo + pages * t / nthreads * page;
     char* b = lo + pages * (t + 1) / nthreads * page;
-    if (t + 1 == nthreads) work(a, b); else pool.emplace_back(work, a, b);
+    bool spawned = false;
+    if (t + 1 < nthreads) {
+      try {  // a thread that cannot be created (resource limits) must not take the process down: do its share here
+        pool.emplace_back(work, a, b);
+        spawned = true;
+      } catch (...) {
+      }
+    }
+    if (!spawned) work(a, b);
   }
   for (auto& th : pool) th.join();
 }
@@ -844,13 +852,18 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       const size_t nstripes = (total - head + stripe - 1) / stripe;
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
       const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), nstripes);
-      for (unsigned t = 0; t < nthreads; ++t)
-        pool.emplace_back([=] {
-          for (size_t k = t; k < nstripes; k += nthreads) {
-            const size_t off = head + k * stripe;
-            touch_range(out + off, std::min(stripe, total - off));
-          }
-        });
+      // helpers are an optimisation: the copy is correct without them (the runtime faults pages in itself,
+      // slowly), so a thread that cannot be created is simply not there
+      try {
+        for (unsigned t = 0; t < nthreads; ++t)
+          pool.emplace_back([=] {
+            for (size_t k = t; k < nstripes; k += nthreads) {
+              const size_t off = head + k * stripe;
+              touch_range(out + off, std::min(stripe, total - off));
+            }
+          });
+      } catch (...) {
+      }
     }
     hipError_t e = hipMemcpyAsync(out, m->d_whole, total, hipMemcpyDeviceToHost, m->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
@@ -885,7 +898,15 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       for (size_t k = 0; k < K; ++k) prefault_range(out + ((pc.pr * K + k) * row_count + pc.r) * N1 * sizeof(double), pc.nrows * N1 * sizeof(double));
     }
   };
-  std::future<void> ready = std::async(std::launch::async, touch, pieces[0]);
+  auto start_touch = [&](const Piece& pc) {
+    try {
+      return std::async(std::launch::async, touch, pc);
+    } catch (...) {  // no thread to be had: do it here
+      touch(pc);
+      return std::future<void>();
+    }
+  };
+  std::future<void> ready = start_touch(pieces[0]);
   bool used[2] = {false, false};
   // on every exit -- errors included -- nothing may still be writing to the caller's buffer
   auto drain = [&] {
@@ -901,8 +922,8 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     rc = launch_grid(m, op, m->d_params + pc.pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + pc.r, pc.nrows, layout,
                      m->stream, 0, accuracy);
     if (rc) { drain(); return rc; }
-    ready.wait();  // pages of this chunk's destination are resident
-    if (c + 1 < pieces.size()) ready = std::async(std::launch::async, touch, pieces[c + 1]);
+    if (ready.valid()) ready.wait();  // pages of this chunk's destination are resident
+    if (c + 1 < pieces.size()) ready = start_touch(pieces[c + 1]);
     hipError_t e = hipEventRecord(m->chunk_done[b], m->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, m->chunk_done[b], 0);
     if (e == hipSuccess) {
