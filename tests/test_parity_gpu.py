@@ -567,3 +567,85 @@ def test_validate_basis_on_domain_agrees_with_the_oracle(name, gpu_lib, capfd):
         lib.validate_basis_on_domain([4], spec.args, [[x0a, x0b]], 1e-3)
     with pytest.raises(Exception):
         lib.validate_basis_on_domain(n, list(spec.args) + [1.0], ss, 1e-3)
+
+
+# ---- launch geometry: any grid shape, row range, layout and batch must give the per-point results --------
+@pytest.mark.parametrize("name", ["hyperbolic", "doc", "d5"])
+def test_geometry_fuzz_sweeps_equal_point_evaluation(name, gpu_lib):
+    """Size-independent property: whatever the grid shape, row range, parameter batch, layout or operation,
+    element [p, i, j] of a sweep is bit for bit what the on-trajectory kernel computes at the point
+    (i*dx0 + x0a, j*dx1 + x1a) -- both run the same stage code, so any difference is an indexing,
+    tiling, staging-table or store-path error.  Covers the row-broadcast path (hyperbolic), the tile path
+    (doc) and the tile path with LDS-resident uniform values (d5), through host and device results."""
+    import torch
+
+    spec, art, lib = devlib(name, gpu_lib)
+    rng = np.random.default_rng(2024)
+    x0a, x0b, x1a, x1b = spec.extent
+    ops = [(gpu_lib.OP_COMPLETE, 6), (gpu_lib.OP_CONSISTENCY, 1), (gpu_lib.OP_RAW, 5), (gpu_lib.OP_EPSILON_V, 1)]
+    shapes = [(1, 1), (1, 257), (300, 1), (2, 2), (33, 255), (32, 256), (31, 513), (97, 64), (5, 1025)]
+    for case in range(36):
+        n0, n1 = shapes[case] if case < len(shapes) else (int(rng.integers(1, 200)), int(rng.integers(1, 900)))
+        P = int(rng.integers(1, 4))
+        op, k = ops[case % len(ops)]
+        layout = gpu_lib.LAYOUT_SOA if (case // 2) % 2 else gpu_lib.LAYOUT_AOS
+        rb = int(rng.integers(0, n0))
+        rc = int(rng.integers(1, n0 - rb + 1))
+        args = np.stack([spec.args * (1.0 + 0.03 * q) for q in range(P)])
+        ss = np.array([[x0a, x0b], [x1a, x1b]])
+        dx0, dx1 = (x0b - x0a) / n0, (x1b - x1a) / n1
+        xs0 = np.arange(rb, rb + rc, dtype=np.float64) * dx0 + x0a
+        xs1 = np.arange(n1, dtype=np.float64) * dx1 + x1a
+        pts = np.stack(np.meshgrid(xs0, xs1, indexing="ij"), axis=-1).reshape(-1, 2)
+        want = np.stack([lib.sweep_on_trajectory(op, args[q], pts).reshape(rc, n1, k) for q in range(P)])  # (P, rc, n1, k)
+        if layout == gpu_lib.LAYOUT_SOA:
+            want = np.moveaxis(want, -1, 1)  # (P, k, rc, n1)
+        got = lib.sweep_host(op, args, ss, n0, n1, row_begin=rb, row_count=rc, layout=layout)
+        what = (name, case, n0, n1, P, op, layout, rb, rc)
+        assert got.reshape(want.shape).shape == want.shape, what
+        assert np.array_equal(got.reshape(want.shape), want, equal_nan=True), what
+        # the device-resident variant of the same sweep
+        out = torch.full((want.size,), -7.0, dtype=torch.float64, device="cuda:0")
+        lib.sweep_device(op, args, out.data_ptr(), out.numel() * 8, ss, n0, n1, row_begin=rb, row_count=rc, layout=layout, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().reshape(want.shape), want, equal_nan=True), what
+
+
+@pytest.mark.parametrize(
+    "name,n0,n1,P,op_name,layout_name",
+    [
+        ("hyperbolic", 70001, 48, 1, "complete", "aos"),  # more than 65535 rows: the store stream takes two launches
+        ("hyperbolic", 66000, 40, 2, "consistency", "aos"),  # single-value planes over more than 65535 rows
+        ("hyperbolic", 3000, 640, 37, "complete", "aos"),  # a parameter batch: several table batches
+        ("hyperbolic", 900, 1201, 3, "raw", "soa"),  # odd row length, SoA: the fallback row kernel
+        ("hyperbolic", 64, 40000, 2, "complete", "soa"),  # very long rows
+        ("doc", 70, 30011, 2, "complete", "aos"),  # tile path, ragged last column tile
+        ("doc", 9000, 130, 1, "raw", "soa"),
+        ("d5", 1500, 700, 2, "complete", "aos"),
+    ],
+)
+def test_large_geometries_equal_point_evaluation(name, n0, n1, P, op_name, layout_name, gpu_lib):
+    """The same property at sizes that cross the launch limits (grid.y = 65535 rows per launch, table
+    batches of at most 64 MiB, column chunks of long rows)."""
+    spec, art, lib = devlib(name, gpu_lib)
+    op, k = {"complete": (gpu_lib.OP_COMPLETE, 6), "consistency": (gpu_lib.OP_CONSISTENCY, 1), "raw": (gpu_lib.OP_RAW, 5)}[op_name]
+    layout = gpu_lib.LAYOUT_SOA if layout_name == "soa" else gpu_lib.LAYOUT_AOS
+    x0a, x0b, x1a, x1b = spec.extent
+    args = np.stack([spec.args * (1.0 + 0.01 * q) for q in range(P)])
+    ss = np.array([[x0a, x0b], [x1a, x1b]])
+    got = lib.sweep_host(op, args, ss, n0, n1, layout=layout)
+    got = got.reshape((P, k, n0, n1) if layout == gpu_lib.LAYOUT_SOA else (P, n0, n1, k))
+    if layout == gpu_lib.LAYOUT_SOA:
+        got = np.moveaxis(got, 1, -1)
+    # a seeded sample of points plus the corners and the seams of the launch limits
+    rng = np.random.default_rng(n0 * 31 + n1)
+    ii = np.concatenate([rng.integers(0, n0, 4000), [0, n0 - 1, min(65534, n0 - 1), min(65535, n0 - 1), min(65536, n0 - 1)]])
+    jj = np.concatenate([rng.integers(0, n1, 4000), [0, n1 - 1, n1 // 2, min(255, n1 - 1), min(256, n1 - 1)]])
+    dx0, dx1 = (x0b - x0a) / n0, (x1b - x1a) / n1
+    pts = np.column_stack([ii.astype(np.float64) * dx0 + x0a, jj.astype(np.float64) * dx1 + x1a])
+    for q in range(P):
+        want = lib.sweep_on_trajectory(op, args[q], pts).reshape(len(ii), k)
+        assert np.array_equal(got[q, ii, jj], want, equal_nan=True), (name, n0, n1, q)
+    # and every row of a row-uniform model repeats its first column
+    if name == "hyperbolic":
+        assert np.array_equal(got, np.broadcast_to(got[:, :, :1], got.shape), equal_nan=True)
