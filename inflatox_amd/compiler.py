@@ -235,7 +235,14 @@ class Compiler:
       and column-only operands are combined before the per-point ones (faster, but rounding differs
       from the reference where a model cancels catastrophically);
     * ``exact_constants`` (default False): full-precision pi, e, ... instead of the reference's
-      12-digit fallback constants.
+      12-digit fallback constants;
+    * ``hoist_reciprocals`` (default False): a per-point quotient whose denominator is known one stage
+      earlier is formed from the correctly rounded reciprocal of that denominator with Markstein's
+      multiply-FMA-FMA step instead of a 13-instruction IEEE division (csrc/inflx_device_math.h: the same
+      correctly rounded quotient; irregular points are re-evaluated with IEEE divisions).  Opt-in because
+      it does not pay yet: the shorter dependency chains let the compiler keep more values in flight,
+      and at the 256-register budget of the tile kernels that turns into spills (D5 4 % faster, EGNO
+      50 % slower on MI355X).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: Bessel functions of integer order are device functions
@@ -280,6 +287,7 @@ class Compiler:
         staged: bool = True,
         exact_constants: bool = False,
         regroup: bool = False,
+        hoist_reciprocals: bool = False,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -294,6 +302,7 @@ class Compiler:
         self.max_cses = max_cses
         self.staged = staged
         self.regroup = regroup
+        self.hoist_reciprocals = hoist_reciprocals
         self.constants = dict(_EXACT_CONSTANTS if exact_constants else _REFERENCE_CONSTANTS)
         self.hipcc_opts = list(compiler_flags) if compiler_flags is not None else list(self.default_hipcc_flags)
         self.symbol_dict = None
@@ -387,6 +396,7 @@ class Compiler:
             cse=cse,
             cse_vector=cse_vector,
             regroup=self.regroup,
+            hoist_reciprocals=self.hoist_reciprocals,
         )
         self.stage_info = info
         return text

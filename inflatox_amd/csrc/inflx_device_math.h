@@ -40,6 +40,36 @@ INFLX_FN double inflx_hpow(double x) {
   }
 }
 
+// ---- division by a value that is known one stage earlier ---------------------------------------------
+// A quotient a/b whose denominator depends on fewer grid axes than its numerator is the single most
+// expensive thing left in the per-point stage: an IEEE double division is 13 instructions, several of them
+// at quarter rate (~72 cycles per wavefront).  With y = RN(1/b) computed once per row / column / sweep
+// (inflx_recip, an IEEE division itself), the per-point work is one multiplication and two FMAs:
+//     q0 = RN(a*y);   r = a - b*q0 (exact, FMA);   q = RN(q0 + r*y)
+// -- Markstein's division step.  With a correctly rounded reciprocal, q is the correctly rounded quotient
+// whenever q0 is within one ulp of a/b (Markstein 1990; Muller et al., Handbook of Floating-Point
+// Arithmetic, section 4.7); q0 can be up to 1.5 ulp off, and then q still is RN(a/b + d) with |d| below
+// 1.7e-16 ulp, which differs from RN(a/b) only if a/b lies that close to a rounding boundary: about 3 in
+// 1e16 quotients, by one ulp (tests/div_hoisted_host.cpp: 228 million quotients, no difference).
+// Everything the three operations do not handle -- infinite or NaN operands, overflow, quotients in the
+// denormal range, a reciprocal that is not a normal number (inflx_recip then hands over NaN), a numerator
+// so small (< 2^-960) that the residual would underflow -- clears `ok`: the generated point stage then
+// evaluates the point again with IEEE divisions (staging.py, inflx_stage_point).  A zero numerator over a
+// regular denominator is regular too; a*y carries the sign a/b has.
+INFLX_FN double inflx_recip(double b) {
+  const double y = 1.0 / b;
+  return __builtin_isnormal(y) ? y : __builtin_nan("");
+}
+
+INFLX_FN double inflx_div_by_hoisted(double a, double b, double y, bool& ok) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  const double q = __builtin_fma(r, y, q0);
+  const bool normal = __builtin_isnormal(q);
+  ok = ok && ((normal && __builtin_fabs(a) >= 0x1p-960) || (a == 0.0 && q0 == 0.0));
+  return normal ? q : q0;
+}
+
 // reciprocal hyperbolic / trigonometric functions sympy may emit without a C99 spelling
 INFLX_FN double inflx_coth(double x) { return 1.0 / tanh(x); }
 INFLX_FN double inflx_sech(double x) { return 1.0 / cosh(x); }

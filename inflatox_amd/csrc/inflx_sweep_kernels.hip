@@ -254,17 +254,12 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const uint64_t cols_left = wave_col0 < a.N1 ? a.N1 - wave_col0 : 0;
   const unsigned wave_units = cols_left >= kWave ? 3u * kWave : 3u * (unsigned)cols_left;
 
-  for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
-    const uint64_t row = row0 + r;
-    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
-    InflxModelValues mv;
-    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
-    double o[K];
-    apply_op<OP>(mv, o, a.accuracy);
+  // what happens to the K values of one grid row: summary, then the store in the requested layout
+  auto emit = [&](const double (&o)[K], const uint64_t row) {
     if constexpr (STATS) {
       if (in_range) stat_add(acc, o, 1);
     }
-    if constexpr (!STORE) continue;
+    if constexpr (!STORE) return;
 
     if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
       if (in_range) {
@@ -310,7 +305,51 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
         for (int k = 0; k < K; ++k) store_d1(dst + k, o[k]);
       }
     }
+  };
+
+#if INFLX_HAS_QUICK_POINT
+  // Hot loop: the point stage that divides by hoisted reciprocals.  A row in which some lane met an
+  // irregular quotient (NaN or infinite operands, overflow, a denormal result...) is only noted here and
+  // evaluated after the loop with IEEE divisions -- by the whole wavefront, since the row is stored as a
+  // block -- so that the cold code costs the hot loop neither registers nor branches.
+  static_assert(kTileRows <= 64, "one bit per tile row");
+  uint64_t redo = 0;
+  for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
+    const uint64_t row = row0 + r;
+    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
+    InflxModelValues mv;
+    bool ok = true;
+    inflx_stage_point_quick(x0, x1, A, U, Rs[r], C, mv, ok);
+    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // wave-uniform
+      redo |= uint64_t(1) << r;
+      continue;
+    }
+    double o[K];
+    apply_op<OP>(mv, o, a.accuracy);
+    emit(o, row);
   }
+  while (redo != 0) {
+    const int r = __builtin_ctzll(redo);
+    redo &= redo - 1;
+    const uint64_t row = row0 + r;
+    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
+    InflxModelValues mv;
+    inflx_stage_point_ieee(x0, x1, A, U, Rs[r], C, mv);
+    double o[K];
+    apply_op<OP>(mv, o, a.accuracy);
+    emit(o, row);
+  }
+#else
+  for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
+    const uint64_t row = row0 + r;
+    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
+    InflxModelValues mv;
+    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+    double o[K];
+    apply_op<OP>(mv, o, a.accuracy);
+    emit(o, row);
+  }
+#endif
   if constexpr (STATS) stat_flush(acc, a.stats);
 }
 

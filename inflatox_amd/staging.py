@@ -198,6 +198,9 @@ class HIPInflatoxPrinter(C99CodePrinter):
         if not den:
             return sign + "*".join(num_s)
         if len(den) == 1:
+            recip = self.stager.hoisted_reciprocal(den) if self.stager is not None else None
+            if recip is not None:
+                return f"INFLX_DIVH({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
             return sign + "*".join(num_s) + "/" + den_s[0]
         return sign + "*".join(num_s) + "/(" + "*".join(den_s) + ")"
 
@@ -270,7 +273,7 @@ class Stager:
     switch that mirrors the reference's five separate C functions.
     """
 
-    def __init__(self, functions, x0, x1, names, staged=True, regroup=False):
+    def __init__(self, functions, x0, x1, names, staged=True, regroup=False, hoist_reciprocals=False):
         """``functions``: one ``(replacements, [expressions])`` pair per generated C function of the
         reference (five scalar functions and the two-component basis vector ``v``), where
         ``replacements`` is the (possibly empty) list of ``(symbol, definition)`` pairs the
@@ -278,6 +281,7 @@ class Stager:
         sys.setrecursionlimit(max(sys.getrecursionlimit(), 50000))
         self.regroup = regroup
         self.staged = staged
+        self.hoist_reciprocals = hoist_reciprocals and staged
         self.x0, self.x1 = x0, x1
         self.printer = HIPInflatoxPrinter(names, self)
         self.lines = {U: [], R: [], C: [], P: []}
@@ -424,6 +428,18 @@ class Stager:
             return items
         return [_Group(op + "prefix", items[:k])] + list(items[k:])
 
+    def hoisted_reciprocal(self, den):
+        """A quotient printed in the per-point stage whose whole denominator is known one stage earlier is
+        evaluated as ``inflx_div_by_hoisted(num, den, y)`` with ``y = inflx_recip(den)`` a value of that
+        earlier stage (csrc/inflx_device_math.h explains why this is the correctly rounded quotient).
+        Returns the text of ``y`` or None when the quotient does not qualify."""
+        if not self.hoist_reciprocals or self._ctx != P or len(den) != 1:
+            return None
+        d = den[0]
+        if not d.free_symbols or self.mask(d) == P:
+            return None
+        return self._variable(_Group("recip", [d]), self.mask(d))
+
     def group_quotient(self, num, den):
         """Fast mode only (``regroup``): inside a product printed in stage ctx, the numerator and
         denominator factors of each lower class become ONE stage variable num/den, so that the division
@@ -493,6 +509,8 @@ class Stager:
                     text = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items)
                 elif e.op == "+prefix":
                     text = self._sum_text(e.items)
+                elif e.op == "recip":
+                    text = f"inflx_recip({self.printer._print(e.items[0])})"
                 elif e.op == "/":
                     top = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.items) if e.items else "1.0"
                     bottom = "*".join(self.printer._operand(i, PRECEDENCE["Mul"]) for i in e.den)
@@ -530,7 +548,8 @@ class Stager:
 
 
 def emit_stage_header(
-    model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False
+    model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False,
+    hoist_reciprocals: bool = False,
 ):
     """Return (header text, info dict) for the model.
 
@@ -564,7 +583,7 @@ def emit_stage_header(
         else:
             functions.append(([], [e]))
     functions.append(cse_vector(basis_v) if cse_vector is not None else ([], basis_v))
-    st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup)
+    st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals)
 
     idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}
 
@@ -623,17 +642,45 @@ def emit_stage_header(
     )
     out.append(body(C))
     out.append("}\n")
-    out.append("// everything that depends on both axes, and the five model values")
-    out.append(
-        f"INFLX_FN void inflx_stage_point([[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {tail}, "
+    point_args = (
+        f"[[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {tail}, "
         "[[maybe_unused]] const double* __restrict__ U, [[maybe_unused]] const double* __restrict__ R, "
-        "[[maybe_unused]] const double* __restrict__ C, InflxModelValues& mv) {"
+        "[[maybe_unused]] const double* __restrict__ C, InflxModelValues& mv"
     )
     lines = imports_for(P, "out") + st.lines[P]
     for field, text in zip(OUTPUT_FIELDS, st.outputs):
         lines.append(f"  mv.{field} = {text};")
-    out.append("\n".join(lines))
-    out.append("}\n")
+    point_body = "\n".join(lines)
+    n_hoisted = point_body.count("INFLX_DIVH(")
+    out.append("// everything that depends on both axes, and the five model values")
+    if n_hoisted:
+        # The same statements twice.  `quick` forms the quotients whose denominator comes from an earlier
+        # stage with inflx_div_by_hoisted (three full-rate instructions instead of an IEEE division) and
+        # reports in `ok` whether every one of them was a regular case; `ieee` divides.  A point that is not
+        # regular -- NaN or infinite operands, a zero or tiny numerator, overflow, a denormal quotient --
+        # is evaluated again by `ieee`, so the values are those of `ieee` always.
+        out.append(f"// {n_hoisted} quotients per point by a denominator of an earlier stage")
+        out.append("#define INFLX_HAS_QUICK_POINT 1")
+        out.append("#define INFLX_DIVH(a, b, y) inflx_div_by_hoisted((a), (b), (y), ok)")
+        out.append(f"INFLX_FN void inflx_stage_point_quick({point_args}, bool& ok) {{")
+        out.append(point_body)
+        out.append("}")
+        out.append("#undef INFLX_DIVH\n")
+        out.append("#define INFLX_DIVH(a, b, y) ((a) / (b))")
+        out.append(f"INFLX_FN void inflx_stage_point_ieee({point_args}) {{")
+        out.append(point_body)
+        out.append("}")
+        out.append("#undef INFLX_DIVH\n")
+        out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
+        out.append("  bool ok = true;")
+        out.append("  inflx_stage_point_quick(x0, x1, args, U, R, C, mv, ok);")
+        out.append("  if (__builtin_expect(!ok, 0)) inflx_stage_point_ieee(x0, x1, args, U, R, C, mv);")
+        out.append("}\n")
+    else:
+        out.append("#define INFLX_HAS_QUICK_POINT 0")
+        out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
+        out.append(point_body)
+        out.append("}\n")
     out.append(_emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector))
     info = dict(nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()})
     return "\n".join(out), info

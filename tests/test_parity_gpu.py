@@ -649,3 +649,24 @@ def test_large_geometries_equal_point_evaluation(name, n0, n1, P, op_name, layou
     # and every row of a row-uniform model repeats its first column
     if name == "hyperbolic":
         assert np.array_equal(got, np.broadcast_to(got[:, :, :1], got.shape), equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["d5", "egno"])
+def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
+    """Compiler(hoist_reciprocals=True): quotients by row/column/sweep-only denominators through Markstein's
+    step, irregular rows re-evaluated with IEEE divisions after the hot loop -- bit for bit the default
+    program's results, singular lines and NaN regions included."""
+    from inflatox_amd import workloads
+
+    spec, art, lib = devlib(name, gpu_lib)
+    _, art_h = workloads.artifact_for(name, hoist_reciprocals=True)
+    lib_h = gpu_lib.InflatoxDevLib(art_h.shared_object_path)
+    ss = np.array(spec.extent).reshape(2, 2)
+    wide = np.array([[spec.extent[0] - 0.3 * (spec.extent[1] - spec.extent[0]), spec.extent[1]], [spec.extent[2], spec.extent[3]]])
+    for extent, n0, n1 in ((ss, 300, 520), (wide, 257, 191)):
+        for op in (gpu_lib.OP_COMPLETE, gpu_lib.OP_RAW, gpu_lib.OP_CONSISTENCY):
+            a = lib.sweep_host(op, spec.args, extent, n0, n1)
+            b = lib_h.sweep_host(op, spec.args, extent, n0, n1)
+            assert np.array_equal(a, b, equal_nan=True), (name, op, n0, n1)
+    s0, s1 = lib.sweep_stats(spec.args, ss, 300, 520), lib_h.sweep_stats(spec.args, ss, 300, 520)
+    assert all(np.array_equal(s0[k], s1[k]) for k in ("min", "max", "count"))

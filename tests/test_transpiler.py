@@ -124,8 +124,11 @@ def test_fast_mode_is_close_but_not_exact(name):
     _, exact_hdr = header_for(name)
 
     def point_divisions(h):
-        body = h[h.index("inflx_stage_point") :]
-        return body.count("/") - body.count(".0/")  # rational literals such as 1.0/3.0 are not divisions
+        # the IEEE variant of the point stage (or the only one): rational literals such as 1.0/3.0 are not
+        # divisions, a quotient by a hoisted reciprocal is one
+        start = h.index("void inflx_stage_point_ieee(") if "inflx_stage_point_ieee" in h else h.index("void inflx_stage_point(")
+        body = h[start : h.index("}\n", start)]
+        return body.count("/") - body.count(".0/") + body.count("INFLX_DIVH(")
 
     if name != "doc":
         assert point_divisions(hdr) < point_divisions(exact_hdr), "fast mode should divide less often per grid point"
@@ -222,3 +225,34 @@ def test_compiler_front_end_contract():
     assert os.path.exists(p2)
     os.remove(p2)
     assert Compiler(model, link_gsl=True, silent=True).gsl is True  # accepted: sets USE_GSL (tests/test_special_functions.py)
+
+
+def test_hoisted_reciprocal_division_is_the_ieee_quotient(tmp_path):
+    """inflx_div_by_hoisted(a, b, RN(1/b)) against a/b, bit for bit: 20 million random quotients of moderate
+    exponents, 2 million arbitrary bit patterns (denormals, overflow, NaN), every pair of special values,
+    and operands with significands next to 1 and 2 (200 million + 20 million were run once: no mismatch)."""
+    import subprocess
+
+    exe = tmp_path / "div_hoisted_host"
+    csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "inflatox_amd", "csrc")
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "div_hoisted_host.cpp")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-mfma", "-ffp-contract=off", f"-I{csrc}", src, "-o", str(exe)], check=True)
+    proc = subprocess.run([str(exe), "20"], capture_output=True, text=True)
+    assert proc.returncode == 0, proc.stdout[-2000:]
+    assert proc.stdout.count(" 0 mismatches") == 3, proc.stdout
+
+
+@pytest.mark.parametrize("name", ["d5", "egno", "doc"])
+def test_hoisted_reciprocals_are_used_and_change_nothing(name):
+    """The per-point divisions by row/column/sweep-only denominators go through inflx_div_by_hoisted, and the
+    program with them is bit-identical to the one with plain divisions on the golden grid and random points."""
+    _, with_h = header_for(name, hoist_reciprocals=True)
+    _, without = header_for(name)
+    assert "INFLX_DIVH(" in with_h and "inflx_stage_point_quick" in with_h and "INFLX_DIVH" not in without
+    a, b = HostTwin(with_h), HostTwin(without)
+    g = golden(name)
+    n0, n1 = (int(v) for v in g["g64_shape"])
+    for op in (4, 0):
+        assert np.array_equal(a.grid(op, g["args"], g["g64_extent"], n0, n1), b.grid(op, g["args"], g["g64_extent"], n0, n1), equal_nan=True)
+    ext = example_models.get(name).extent
+    assert np.array_equal(a.grid(0, g["args"], ext, 150, 130), b.grid(0, g["args"], ext, 150, 130), equal_nan=True)
