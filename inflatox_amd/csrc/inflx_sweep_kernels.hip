@@ -430,7 +430,8 @@ __device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
   const uint64_t row = (uint64_t)a.stream_row0 + blockIdx.y;
   const unsigned p = blockIdx.z;
   const uint64_t slab_row = (uint64_t)p * a.row_count + row;
-  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + k % a.table_replicas) * 8;
+  // table_replicas is a power of two (the host guarantees it): a mask, not the 20-instruction modulo
+  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + (k & (a.table_replicas - 1))) * 8;
   const uint64_t u = (uint64_t)k * kThreads + threadIdx.x;
   // u mod 3 == (k + tid) mod 3 because 256 == 1 (mod 3)
   const unsigned phase = (k % 3 + threadIdx.x) % 3;
@@ -457,7 +458,7 @@ __device__ __forceinline__ void sweep_rowstream_planes(const InflxSweepArgs& a) 
   const unsigned p = blockIdx.z / a.stream_planes;
   const unsigned k = blockIdx.z - p * a.stream_planes;
   const uint64_t slab_row = (uint64_t)p * a.row_count + row;
-  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + piece % a.table_replicas) * 8;
+  const double* __restrict__ t = a.row_table + (slab_row * a.table_replicas + (piece & (a.table_replicas - 1))) * 8;
   double v = t[k];
   asm volatile("" : "+s"(v));
   const uint64_t u = (uint64_t)piece * kThreads + threadIdx.x;
