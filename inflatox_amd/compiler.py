@@ -240,9 +240,9 @@ class Compiler:
       earlier is formed from the correctly rounded reciprocal of that denominator with Markstein's
       multiply-FMA-FMA step instead of a 13-instruction IEEE division (csrc/inflx_device_math.h: the same
       correctly rounded quotient; irregular points are re-evaluated with IEEE divisions).  Opt-in because
-      it does not pay yet: the shorter dependency chains let the compiler keep more values in flight,
-      and at the 256-register budget of the tile kernels that turns into spills (D5 4 % faster, EGNO
-      50 % slower on MI355X).
+      it does not pay enough: the default program's independent divisions already overlap well, and the
+      quick stage's register pressure costs what the shorter divisions gain (D5 5 % faster, EGNO 10 %
+      slower on MI355X).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: Bessel functions of integer order are device functions
