@@ -144,7 +144,10 @@ class GSLInflatoxPrinter(CInflatoxPrinter):
     def _bessel(self, expr):
         letter, own, integer_name, real_name = self._FAMILIES[expr.func.__name__]
         self.update_preamble(self.BESSELH)
-        nu, x = expr.args[0], self._print_Symbol(expr.args[1])  # the reference prints the argument as a symbol
+        # the reference prints the argument with _print_Symbol, i.e. it only accepts a bare symbol there (anything
+        # else raises inside sympy); a general argument is printed as an expression here
+        arg = expr.args[1]
+        nu, x = expr.args[0], (self._print_Symbol(arg) if arg.is_Symbol else self._print(arg))
         if nu.is_integer:
             n = int(float(self._print_Symbol(nu)))
             if str(n) in own:
@@ -245,9 +248,9 @@ class Compiler:
       slower on MI355X).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
-    (compiler.py:123-212).  Here nothing is linked: Bessel functions of integer order are device functions
-    of this package (csrc/inflx_sf.h) and print with or without the flag, which only sets the artefact's
-    ``USE_GSL`` global; Bessel functions of real order and hypergeometric functions raise
+    (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order, spherical
+    ones of integer order) and 0F1 are device functions of this package (csrc/inflx_sf.h) and print with or
+    without the flag, which only sets the artefact's ``USE_GSL`` global; 1F1, 2F1 and 2F0 raise
     ``NotImplementedError`` while the code is generated.
     """
 

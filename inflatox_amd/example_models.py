@@ -215,3 +215,14 @@ def bessel_toy():
     m, L = sp.symbols("m L")
     potential = m**2 * (2 + sp.besselj(0, phi)) * (1 + sp.Rational(1, 10) * sp.cos(theta))
     return [phi, theta], [[1, 0], [0, L**2 * (1 + phi**2)]], potential
+
+
+def bessel_real():
+    """Bessel functions of real order (a fixed one and a parameter) and 0F1: the functions the reference reaches
+    through gsl_sf_bessel_*nu and gsl_sf_hyperg_0F1.  The parameter nu must be >= 2 for the Hesse matrix
+    (its second derivatives bring in K_(nu-2); GSL, like the device functions, rejects negative orders)."""
+    phi, theta = sp.symbols("phi theta")
+    m, nu = sp.symbols("m nu")
+    shape = 3 + sp.besselj(sp.Rational(5, 2), phi) + sp.besselk(nu, phi + 1) + sp.hyper([], [sp.Rational(3, 2)], -(phi**2) / 4)
+    potential = m**2 * shape * (1 + sp.cos(theta) / 10)
+    return [phi, theta], [[1, 0], [0, 1 + phi**2]], potential

@@ -145,7 +145,10 @@ class HIPInflatoxPrinter(C99CodePrinter):
     def _bessel(self, expr, letter, named_orders, general):
         nu, arg = expr.args
         if not (nu.is_number and nu.is_integer):
-            raise NotImplementedError(f"{expr.func.__name__} of non-integer or symbolic order {nu} has no device implementation (integer orders only)")
+            # real or symbolic order: gsl_sf_bessel_{J,Y,I,K}nu(nu, x) in the reference (nu >= 0)
+            if letter not in "JYIK":
+                raise NotImplementedError(f"{expr.func.__name__} of non-integer order {nu}: the reference has no such function either (compiler.py:199-212)")
+            return f"inflx_sf_bessel_{letter}nu({self._print(nu)}, {self._print(arg)})"
         n = int(nu)
         x = self._print(arg)
         if n in named_orders:
@@ -171,7 +174,12 @@ class HIPInflatoxPrinter(C99CodePrinter):
         return self._bessel(expr, "y", (0, 1, 2), "l")
 
     def _print_hyper(self, expr):
-        raise NotImplementedError("hypergeometric functions (gsl_sf_hyperg_* in the reference) have no device implementation")
+        ap, bq, x = expr.args
+        if (len(ap), len(bq)) == (0, 1):
+            return f"inflx_sf_hyperg_0F1({self._print(bq[0])}, {self._print(x)})"
+        raise NotImplementedError(
+            f"hypergeometric function {len(ap)}F{len(bq)} (gsl_sf_hyperg_* in the reference) has no device implementation; only 0F1 is available"
+        )
 
     def _operand(self, item, level):
         """``parenthesize`` for an operand that may have been replaced by a stage variable."""

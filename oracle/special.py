@@ -79,3 +79,26 @@ def raw_values(model, symbol_dictionary: dict, args, pts) -> np.ndarray:
     with np.errstate(all="ignore"):
         vals = f(pts[:, 0], pts[:, 1], *[float(a) for a in args])
     return np.stack([np.broadcast_to(np.asarray(v, dtype=np.float64), pts.shape[:1]) for v in vals], axis=1)
+
+
+def raw_values_mp(model, symbol_dictionary: dict, args, pts, dps: int = 30) -> np.ndarray:
+    """The same five values through ``sympy.lambdify(..., "mpmath")`` -- for expressions scipy's printer does
+    not know (hypergeometric functions, Bessel functions of real order with derivatives).  Small n only."""
+    import mpmath as mp
+    import sympy
+
+    exprs, _ = lambdify_raw(model)
+    by_name = {}
+    for e in exprs:
+        for s in sympy.sympify(e).free_symbols:
+            by_name[sympy.printing.c.C99CodePrinter()._print_Symbol(s)] = s
+    order = sorted(((slot, name) for name, slot in symbol_dictionary.items() if slot.startswith("args[")), key=lambda t: int(t[0][5:-1]))
+    x0, x1 = model.coordinates
+    params = [by_name.get(name, sympy.Symbol(name)) for _, name in order]
+    f = sympy.lambdify([x0, x1] + params, exprs, modules="mpmath")
+    out = np.zeros((len(pts), 5))
+    with mp.workdps(dps):
+        for k, (a, b) in enumerate(np.asarray(pts, dtype=np.float64)):
+            vals = f(mp.mpf(float(a)), mp.mpf(float(b)), *[mp.mpf(float(v)) for v in args])
+            out[k] = [float(mp.re(v)) for v in vals]
+    return out

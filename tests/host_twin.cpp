@@ -18,6 +18,9 @@ using std::cos;
 using std::cosh;
 using std::exp;
 using std::fabs;
+using std::floor;
+using std::fmax;
+using std::lgamma;
 using std::log;
 using std::pow;
 using std::sin;
