@@ -670,3 +670,41 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
             assert np.array_equal(a, b, equal_nan=True), (name, op, n0, n1)
     s0, s1 = lib.sweep_stats(spec.args, ss, 300, 520), lib_h.sweep_stats(spec.args, ss, 300, 520)
     assert all(np.array_equal(s0[k], s1[k]) for k in ("min", "max", "count"))
+
+
+def test_open_close_cycles_do_not_leak_and_models_coexist(gpu_lib):
+    """Handles are independent (two models, and one artefact opened twice, interleave freely) and closing
+    gives back everything a model took: 150 open / sweep / close cycles leave the free HBM where it was."""
+    import gc
+
+    import torch
+
+    spec_h, art_h, lib_h = devlib("hyperbolic", gpu_lib)
+    spec_d, art_d, lib_d = devlib("doc", gpu_lib)
+    second = gpu_lib.InflatoxDevLib(art_d.shared_object_path)
+    ss_h, ss_d = np.array(spec_h.extent).reshape(2, 2), np.array(spec_d.extent).reshape(2, 2)
+    a1 = lib_d.sweep_host(gpu_lib.OP_COMPLETE, spec_d.args, ss_d, 120, 90)
+    b1 = lib_h.sweep_host(gpu_lib.OP_COMPLETE, spec_h.args, ss_h, 100, 64)
+    a2 = second.sweep_host(gpu_lib.OP_COMPLETE, spec_d.args, ss_d, 120, 90)
+    b2 = lib_h.sweep_host(gpu_lib.OP_COMPLETE, spec_h.args, ss_h, 100, 64)
+    assert np.array_equal(a1, a2, equal_nan=True) and np.array_equal(b1, b2, equal_nan=True)
+    del second
+    gc.collect()
+    torch.cuda.synchronize()
+
+    def cycle():
+        lib = gpu_lib.InflatoxDevLib(art_d.shared_object_path)
+        lib.sweep_host(gpu_lib.OP_COMPLETE, spec_d.args, ss_d, 300, 200)
+        lib.sweep_stats(spec_d.args, ss_d, 64, 64)
+        lib.sweep_on_trajectory(gpu_lib.OP_RAW, spec_d.args, np.array([[2.0, -2.0]]))
+        del lib
+
+    for _ in range(10):  # let allocator pools settle
+        cycle()
+    gc.collect()
+    free0, _ = torch.cuda.mem_get_info()
+    for _ in range(150):
+        cycle()
+    gc.collect()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 32 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of HBM did not come back"
