@@ -708,3 +708,38 @@ def test_open_close_cycles_do_not_leak_and_models_coexist(gpu_lib):
     gc.collect()
     free1, _ = torch.cuda.mem_get_info()
     assert free0 - free1 < 32 << 20, f"{(free0 - free1) / 2**20:.1f} MiB of HBM did not come back"
+
+
+def test_concurrent_sweeps_from_two_threads(gpu_lib):
+    """INTEGRATION.md's threading contract: calls on different handles may overlap (ctypes releases the GIL;
+    every handle has its own streams and buffers, the error text is thread-local)."""
+    import threading
+
+    spec_h, art_h, _ = devlib("hyperbolic", gpu_lib)
+    spec_d, art_d, _ = devlib("d5", gpu_lib)
+    jobs = [(spec_h, art_h, 700, 512), (spec_d, art_d, 300, 260), (spec_d, art_d, 300, 260)]
+    want = []
+    for spec, art, n0, n1 in jobs:
+        lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+        want.append(lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, np.array(spec.extent).reshape(2, 2), n0, n1))
+    got, errors = [None] * len(jobs), []
+
+    def work(k):
+        try:
+            spec, art, n0, n1 = jobs[k]
+            lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+            for _ in range(8):
+                got[k] = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, np.array(spec.extent).reshape(2, 2), n0, n1)
+            with pytest.raises(Exception):  # an error in one thread does not disturb the others
+                lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args[:-1], np.array(spec.extent).reshape(2, 2), n0, n1)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for g, w in zip(got, want):
+        assert np.array_equal(g, w, equal_nan=True)
