@@ -157,7 +157,10 @@ def main():
     assert plan.axis == "param" and plan.p_count == 1 and plan.row_count == N0
     args = all_rows[plan.p_begin]
     out = torch.empty((N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
-    stream = torch.cuda.current_stream().cuda_stream
+    # a stream of our own: torch's default stream has the NULL handle, which the C ABI reads as "the model's
+    # own stream"; with an explicit one the HIP events below are recorded on the stream the kernels run on
+    launch_stream = torch.cuda.Stream(device=f"cuda:{local_rank}")
+    stream = launch_stream.cuda_stream
     nbytes = out.numel() * 8
 
     def step():
@@ -169,14 +172,20 @@ def main():
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
+    # HIP events on the launch stream bracket the same region (torch's current stream is the stream the
+    # sweeps are enqueued on): device time per step, next to the wall-clock figure the value is computed from
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record(launch_stream)
     for _ in range(opt.steps):
         step()
+    ev1.record(launch_stream)
     torch.cuda.synchronize()
     if distributed:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    step_ms_events = ev0.elapsed_time(ev1) / opt.steps
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device=comm_device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -239,6 +248,7 @@ def main():
                 "kernel": kernel,
                 "kernel_ms": ms_kernel,
                 "sweep_ms": ms_sweep,
+                "timed_region_ms_per_step_hip_events": step_ms_events,
                 "kernels_per_step": ["inflx_sweep_rowvals_complete", "inflx_sweep_rowstream6"] if row_path else ["inflx_sweep_tile_complete"],
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * points,
             },
