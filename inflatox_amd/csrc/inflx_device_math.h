@@ -12,6 +12,15 @@
 #include <hip/hip_runtime.h>
 #define INFLX_FN __device__ __forceinline__
 #endif
+// the long special-function routines (continued fractions, double-double series) are real functions: a
+// model may call them a dozen times, and every kernel of the code object would carry every copy
+#ifndef INFLX_FN_NOINLINE
+#ifdef INFLX_HOST_TWIN
+#define INFLX_FN_NOINLINE static __attribute__((noinline))
+#else
+#define INFLX_FN_NOINLINE __device__ __noinline__
+#endif
+#endif
 
 // x^N for a compile-time integer N >= 1 by binary exponentiation (at most 2*log2(N) multiplies,
 // error <= (N-1) half-ulps; the reference calls libm pow(x, N) here, < 1 ulp).

@@ -175,10 +175,13 @@ class HIPInflatoxPrinter(C99CodePrinter):
 
     def _print_hyper(self, expr):
         ap, bq, x = expr.args
-        if (len(ap), len(bq)) == (0, 1):
-            return f"inflx_sf_hyperg_0F1({self._print(bq[0])}, {self._print(x)})"
+        kind = (len(ap), len(bq))
+        if kind in ((0, 1), (1, 1), (2, 1)):
+            operands = ", ".join(self._print(v) for v in list(ap) + list(bq) + [x])
+            return f"inflx_sf_hyperg_{kind[0]}F{kind[1]}({operands})"
         raise NotImplementedError(
-            f"hypergeometric function {len(ap)}F{len(bq)} (gsl_sf_hyperg_* in the reference) has no device implementation; only 0F1 is available"
+            f"hypergeometric function {kind[0]}F{kind[1]} has no device implementation (0F1, 1F1 and 2F1 are available; the reference's "
+            "gsl_sf_hyperg_2F0 is not)"
         )
 
     def _operand(self, item, level):

@@ -1,7 +1,7 @@
 """CPU stand-in for the reference's GSL special functions -- TEST INFRASTRUCTURE ONLY.
 
-The reference evaluates sympy's ``besselj/bessely/besseli/besselk/jn/yn`` through GSL
-(``gsl_sf_bessel_*``, python/inflatox/compiler.py:123-212; GSL is a system library of the user's machine,
+The reference evaluates sympy's ``besselj/bessely/besseli/besselk/jn/yn`` and ``hyper`` through GSL
+(``gsl_sf_bessel_*``, ``gsl_sf_hyperg_*``; python/inflatox/compiler.py:123-212; GSL is a system library of the user's machine,
 no version is pinned by the reference).  GSL is absent from this image, so generated C that calls it cannot
 be compiled here: **parity against GSL itself is unpinned**.  The functions are standard, though, and any
 correct double-precision implementation agrees with GSL to a few ulps of the function's local amplitude;

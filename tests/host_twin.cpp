@@ -21,6 +21,8 @@ using std::fabs;
 using std::floor;
 using std::fmax;
 using std::lgamma;
+using std::log1p;
+using std::tgamma;
 using std::log;
 using std::pow;
 using std::sin;

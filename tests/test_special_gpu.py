@@ -84,3 +84,29 @@ def test_real_order_bessel_and_0F1_on_the_gpu(gpu_lib):
     # nu below 2 brings a negative order into the Hesse matrix: NaN there, as GSL's domain error would have it
     bad = al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 1.5]), np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), 4, 4)
     assert np.isfinite(bad[..., 0]).all() and np.isnan(bad[..., 1]).all()
+
+
+def test_hypergeometric_model_on_the_gpu(gpu_lib):
+    """1F1 and 2F1 (double-double series, noinline device functions) inside a model: raw values of a sweep
+    against a 30-digit mpmath evaluation of the same sympy expressions; device-resident sweep included."""
+    import torch
+    from conftest import generalised_al
+    from inflatox_amd import example_models
+
+    model, comp, art = _build(example_models.hypergeometric, "hypergeometric", assertions=False, simplify=False)
+    al = generalised_al(art)
+    args = np.array([0.9, 0.7, 2.3])
+    n0, n1, ext = 18, 6, (0.3, 9.0, 0.2, 2.9)
+    ss = np.array([[ext[0], ext[1]], [ext[2], ext[3]]])
+    want = special.raw_values_mp(model, comp.symbol_dict, args, oracle.grid_points(ext, n0, n1))
+    raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, ss, n0, n1).reshape(-1, 5)
+    scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
+    assert np.isfinite(want).all() and (np.abs(raw - want) / scale).max() < 1e-10
+    # a larger sweep through the tile kernels: finite everywhere, equal to the per-point evaluation
+    big = al.dylib.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 300, 260)
+    assert np.isfinite(big[..., 1]).all()
+    out = torch.empty(big.size, dtype=torch.float64, device="cuda:0")
+    al.dylib.sweep_device(gpu_lib.OP_COMPLETE, args, out.data_ptr(), out.numel() * 8, ss, 300, 260, stream=torch.cuda.current_stream().cuda_stream)
+    al.dylib.synchronize()
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy().reshape(big.shape), big, equal_nan=True)
