@@ -266,7 +266,7 @@ class Compiler:
         "-fno-fast-math",
         # contraction only within a source statement, like the clang (zig cc) the reference compiles
         # with; hipcc's default `fast` also fuses across statements, which measurably moves results
-        # away from the reference where a model cancels catastrophically (scripts/contract_experiment.py)
+        # away from the reference where a model cancels catastrophically (tests/tools/contract_experiment.py)
         "-ffp-contract=on",
         "-fno-gpu-rdc",
         "-Wall",
