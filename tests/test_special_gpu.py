@@ -37,6 +37,15 @@ def test_every_device_bessel_function_against_mpmath(gpu_lib):
             want = special.mp_bessel(kind, order, xi)
             budget = (2e-15 + 2e-16 * order) * max(1.0, xi / 10.0) * special.mp_amplitude(kind, order, xi)
             assert abs(float(want - float(g))) <= budget, (kind, order, xi, g, float(want))
+    # the potential depends on phi alone: a grid sweep takes the row-broadcast kernels, which call the same
+    # device functions from the per-row evaluation -- bit for bit the per-point results
+    p = np.full(art.n_parameters, 0.1)
+    n0, n1, ss = 150, 64, np.array([[0.3, 20.0], [0.0, 1.0]])
+    grid = cond.dylib.sweep_host(gpu_lib.OP_RAW, p, ss, n0, n1)
+    x0 = np.arange(n0, dtype=np.float64) * ((20.0 - 0.3) / n0) + 0.3
+    line = cond.dylib.sweep_on_trajectory(gpu_lib.OP_RAW, p, np.stack([x0, np.zeros(n0)], axis=1))
+    assert np.isfinite(grid[..., 0]).all()
+    assert np.array_equal(grid, np.broadcast_to(line[:, None, :], grid.shape), equal_nan=True)
 
 
 def test_bessel_model_sweep_against_scipy_stand_in(gpu_lib):
