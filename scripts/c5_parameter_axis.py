@@ -32,12 +32,20 @@ def main():
     ap.add_argument("--grid", type=int, default=8192)
     opt = ap.parse_args()
     rank, world, local = (int(os.environ.get(k, d)) for k, d in (("RANK", 0), ("WORLD_SIZE", 1), ("LOCAL_RANK", 0)))
+    # INFLX_BENCH_REHEARSE=1 (as in bench.py): ranks share the visible GPUs and talk over gloo -- a one-GPU rehearsal
+    rehearse = os.environ.get("INFLX_BENCH_REHEARSE") == "1"
+    if rehearse:
+        local %= max(1, torch.cuda.device_count())
+    comm = "cpu" if rehearse else f"cuda:{local}"
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        if rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
     P = opt.rows or 64 * world
     n = opt.grid
     spec, art = workloads.artifact_for("hyperbolic")
@@ -58,10 +66,10 @@ def main():
     t_sweep = time.perf_counter() - t0
     t0 = time.perf_counter()
     local_summary = lib.sweep_stats(mine, spec.extent, n, n, row_begin=plan.row_begin, row_count=plan.row_count)
-    total = all_reduce_summary(local_summary, device=f"cuda:{local}") if world > 1 else local_summary
+    total = all_reduce_summary(local_summary, device=comm) if world > 1 else local_summary
     t_stats = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([t_sweep], dtype=torch.float64, device=f"cuda:{local}")
+        t = torch.tensor([t_sweep], dtype=torch.float64, device=comm)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         t_sweep = float(t.item())
     points = P * n * n if plan.axis == "param" else P * n * n
