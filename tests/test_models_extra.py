@@ -36,13 +36,17 @@ def _build(name):
         V = a * sp.exp(-x * y / 4) + b * sp.log(2 + sp.sin(x) * sp.cos(y)) + sp.atan(x + y)
         G = [[sp.cosh(y / 3) ** 2, 0], [0, 1 + x**2]]
         args, ext = [1.5, 0.8], (-1.0, 1.0, -1.0, 1.0)
+    elif name == "libm_breadth":  # erf/erfc, cbrt, asinh, softplus, 2**x, atan2 in the metric, a Piecewise branch
+        V = a * sp.erf(x) + b * sp.cbrt(1 + y**2) + sp.asinh(x * y) + sp.log(1 + sp.exp(x)) + sp.Piecewise((x**2 * y, x > 0), (0, True)) + sp.erfc(y / 2) * 2 ** (x / 3)
+        G = [[1 + sp.tanh(y) ** 2, 0], [0, 2 + sp.atan2(x, 1 + y**2) ** 2]]
+        args, ext = [0.8, 1.2], (-1.5, 2.0, -1.0, 1.5)
     else:
         raise KeyError(name)
     model = InflationModelBuilder.new([x, y], G, V, model_name=name, silent=True, init_sympy_printing=False, simplify=False, assertions=False).build()
     return model, np.array(args), ext
 
 
-MODELS = ("column_only", "abs_and_sign", "symbolic_exponent", "transcendental")
+MODELS = ("column_only", "abs_and_sign", "symbolic_exponent", "transcendental", "libm_breadth")
 
 
 @functools.lru_cache(maxsize=None)
