@@ -249,9 +249,8 @@ class Compiler:
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order, spherical
-    ones of integer order) and 0F1, 1F1, 2F1 are device functions of this package (csrc/inflx_sf.h) and print
-    with or without the flag, which only sets the artefact's ``USE_GSL`` global; 2F0 raises
-    ``NotImplementedError`` while the code is generated.
+    ones of integer order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
+    print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
     """
 
     c_prefix = "inflx_auto_"

@@ -229,10 +229,11 @@ def bessel_real():
 
 
 def hypergeometric():
-    """1F1 and 2F1 in a potential (gsl_sf_hyperg_1F1 / gsl_sf_hyperg_2F1 in the reference); the parameters a and
+    """1F1, 2F1 and 2F0 in a potential (gsl_sf_hyperg_1F1 / _2F1 / _2F0 in the reference); the parameters a and
     c of the Gauss function are model parameters."""
     phi, theta = sp.symbols("phi theta")
     m, a, c = sp.symbols("m a c")
     shape = 2 + sp.hyper([sp.Rational(1, 2)], [sp.Rational(3, 2)], -(phi**2)) + sp.hyper([a, 1], [c], phi / 10 - sp.Rational(1, 2))
+    shape += sp.hyper([1, sp.Rational(5, 2)], [], -phi / 4)  # 2F0: gsl_sf_hyperg_2F0, x < 0
     potential = m**2 * shape * (1 + sp.cos(theta) / 10)
     return [phi, theta], [[1, 0], [0, 1 + phi**2]], potential

@@ -176,13 +176,11 @@ class HIPInflatoxPrinter(C99CodePrinter):
     def _print_hyper(self, expr):
         ap, bq, x = expr.args
         kind = (len(ap), len(bq))
-        if kind in ((0, 1), (1, 1), (2, 1)):
+        if kind in ((0, 1), (1, 1), (2, 1), (2, 0)):
             operands = ", ".join(self._print(v) for v in list(ap) + list(bq) + [x])
             return f"inflx_sf_hyperg_{kind[0]}F{kind[1]}({operands})"
-        raise NotImplementedError(
-            f"hypergeometric function {kind[0]}F{kind[1]} has no device implementation (0F1, 1F1 and 2F1 are available; the reference's "
-            "gsl_sf_hyperg_2F0 is not)"
-        )
+        # the reference's printer refuses these as well (compiler.py:173-175)
+        raise NotImplementedError(f"hypergeometric function {kind[0]}F{kind[1]}: only 0F1, 1F1, 2F1 and 2F0 exist (here as in the reference)")
 
     def _operand(self, item, level):
         """``parenthesize`` for an operand that may have been replaced by a stage variable."""

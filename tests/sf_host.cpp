@@ -29,5 +29,6 @@ F2(Jn) F2(Yn) F2(In) F2(Kn) F2(jl) F2(yl)
 F3(Jnu) F3(Ynu) F3(Inu) F3(Knu)
 void sf_1F1(double a, double b, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_1F1(a, b, x[i]); }
 void sf_2F1(double a, double b, double c, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_2F1(a, b, c, x[i]); }
+void sf_2F0(double a, double b, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_2F0(a, b, x[i]); }
 void sf_0F1(double c, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_0F1(c, x[i]); }
 }

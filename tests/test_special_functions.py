@@ -142,7 +142,7 @@ def test_device_printer_and_unsupported_functions():
     assert "inflx_sf_bessel" not in point_stage
     phi, theta = model.coordinates
     nu = sympy.Symbol("nu")
-    for bad in (sympy.hyper([1, 2], [], -phi), sympy.hyper([1, 2, 3], [4, 5], phi), sympy.yn(nu, phi)):
+    for bad in (sympy.hyper([1, 2, 3], [4, 5], phi), sympy.hyper([1], [], phi / 9), sympy.yn(nu, phi)):
         fields, metric, _ = example_models.bessel_toy()
         m2 = InflationModelBuilder.new(fields, metric, bad + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
         with pytest.raises((NotImplementedError, KeyError, Exception)):  # KeyError / Exception: the reference printer's own refusals
@@ -240,9 +240,9 @@ def test_real_order_and_0F1_model_on_host_twin_against_mpmath():
     want = special.raw_values_mp(model, comp.symbol_dict, args, pts)
     scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
     assert np.isfinite(want).all() and (np.abs(got - want) / scale).max() < 1e-10
-    # 2F0 and spherical functions of non-integer order stay unsupported -- loudly
+    # what the reference's printer refuses is refused here as well -- loudly
     phi = model.coordinates[0]
-    for bad in (sympy.hyper([1, 2], [], -phi), sympy.jn(sympy.Rational(1, 2), phi)):
+    for bad in (sympy.hyper([1, 2, 3], [4], phi / 9), sympy.jn(sympy.Rational(1, 2), phi)):
         m2 = InflationModelBuilder.new(fields, metric, bad + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
         with pytest.raises((NotImplementedError, KeyError, Exception)):  # KeyError / Exception: the reference printer's own refusals
             Compiler(m2, silent=True, link_gsl=True)._generate_hip_header()
@@ -306,7 +306,7 @@ def test_hypergeometric_model_on_host_twin_against_mpmath():
     model = InflationModelBuilder.new(fields, metric, potential, model_name="hypergeometric", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
     comp = Compiler(model, silent=True, link_gsl=True)
     hdr = comp._generate_hip_header()
-    assert "inflx_sf_hyperg_1F1(" in hdr and "inflx_sf_hyperg_2F1(" in hdr
+    assert "inflx_sf_hyperg_1F1(" in hdr and "inflx_sf_hyperg_2F1(" in hdr and "inflx_sf_hyperg_2F0(" in hdr
     assert comp.symbol_dict == {"phi": "x[0]", "theta": "x[1]", "m": "args[0]", "a": "args[1]", "c": "args[2]"}
     tw = HostTwin(hdr)
     args = np.array([0.9, 0.7, 2.3])
@@ -319,6 +319,35 @@ def test_hypergeometric_model_on_host_twin_against_mpmath():
     scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
     assert np.isfinite(want).all() and (np.abs(got - want) / scale).max() < 1e-10
     phi = model.coordinates[0]
-    m2 = InflationModelBuilder.new(fields, metric, sympy.hyper([1, 2], [], -phi) + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
-    with pytest.raises(NotImplementedError):  # 2F0 stays open
-        Compiler(m2, silent=True, link_gsl=True)._generate_hip_header()
+    theta, m = model.coordinates[1], sympy.Symbol("m")
+    v2 = m**2 * (2 + sympy.hyper([1, sympy.Rational(5, 2)], [], -phi / 4)) * (1 + sympy.cos(theta) / 10)
+    m2 = InflationModelBuilder.new(fields, metric, v2, model_name="two_f_zero", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
+    c2 = Compiler(m2, silent=True, link_gsl=True)
+    h2 = c2._generate_hip_header()
+    assert "inflx_sf_hyperg_2F0(" in h2
+    got2 = HostTwin(h2).grid(4, np.array([1.1]), ext, 6, 3).reshape(-1, 5)
+    want2 = special.raw_values_mp(m2, c2.symbol_dict, np.array([1.1]), oracle.grid_points(ext, 6, 3))
+    scale2 = np.maximum(np.abs(want2), np.abs(want2).max(axis=0, keepdims=True) * 1e-3)
+    assert np.isfinite(want2).all() and (np.abs(got2 - want2) / scale2).max() < 1e-10
+
+
+def test_hyperg_2F0_on_host_against_mpmath(sf):
+    """x < 0 (GSL's domain).  Right to 1e-12 (measured 1.5e-14) wherever a value is returned; declined (NaN) only
+    when neither parameter is a non-positive integer, both are below 0.25 and |x| is too large for the asymptotic
+    series."""
+    import mpmath as mp
+
+    rng = np.random.default_rng(41)
+    x = -np.concatenate([10.0 ** rng.uniform(-4, 4, 20), [1e-3, 0.02, 0.03, 0.05, 0.1, 0.3, 1.0, 3.0, 10.0, 100.0]])
+    params = [(0.5, 0.5), (1.0, 2.0), (2.5, -1.5), (0.3, 3.7), (4.0, 0.2), (7.5, 2.0), (20.0, 3.0), (35.0, -7.5), (-2.0, 3.3), (-3.0, -4.0), (1.0, -0.5)]
+    params += [(float(rng.uniform(0.25, 12)), float(rng.uniform(-6, 12))) for _ in range(8)]
+    with mp.workdps(40):
+        for a, b in params:
+            for xi, g in zip(x, _hyp(sf, "2F0", (a, b), x)):
+                want = mp.hyp2f0(a, b, mp.mpf(float(xi)))
+                assert not np.isnan(g), (a, b, xi)
+                assert abs(float((mp.mpf(float(g)) - want) / want)) < 1e-12, (a, b, xi, g, float(want))
+    assert np.isnan(_hyp(sf, "2F0", (1.0, 2.0), np.array([0.5])))[0]  # x > 0: GSL's domain error
+    assert _hyp(sf, "2F0", (1.0, 2.0), np.array([0.0]))[0] == 1.0
+    assert np.isnan(_hyp(sf, "2F0", (0.1, 0.1), np.array([-1.0])))[0]  # declined
+    assert abs(_hyp(sf, "2F0", (0.1, 0.1), np.array([-0.01]))[0] / float(mp.hyp2f0(0.1, 0.1, -0.01)) - 1) < 1e-13  # asymptotic range
