@@ -9,6 +9,7 @@ using std::fmax;
 using std::floor;
 using std::lgamma;
 using std::tgamma;
+using std::tan;
 using std::log1p;
 using std::sinh;
 using std::cosh;

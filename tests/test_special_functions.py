@@ -276,8 +276,8 @@ def test_hyperg_1F1_on_host_against_mpmath(sf):
 
 
 def test_hyperg_2F1_on_host_against_mpmath(sf):
-    """Right to 1e-12 wherever a value is returned; NaN (declined) only for x within 1e-3 of 1 together with an
-    integer c - a - b, outside -1 <= x < 1, and at the poles of c."""
+    """Right to 1e-12 wherever a value is returned; NaN only outside -1 <= x < 1, at the poles of c, and (declined)
+    next to x = 1 when c - a - b is within 1e-3 of an integer without being one."""
     import mpmath as mp
 
     rng = np.random.default_rng(37)
@@ -298,7 +298,15 @@ def test_hyperg_2F1_on_host_against_mpmath(sf):
     assert declined == 0, declined
     assert np.isnan(_hyp(sf, "2F1", (1.0, 1.0, 2.0), np.array([1.0, 1.5, -1.5]))).all()  # GSL: |x| < 1
     assert np.isnan(_hyp(sf, "2F1", (1.0, 1.0, -1.0), np.array([0.3])))[0]
-    assert np.isnan(_hyp(sf, "2F1", (1.0, 1.0, 2.0), np.array([0.9999])))[0]  # integer c-a-b this close to 1: declined, not guessed
+    # c - a - b an integer (elliptic integrals, logarithms...): the logarithmic connection formula right up to x = 1
+    near_one = np.array([0.95, 0.999, 0.999999, 1 - 1e-12])
+    with mp.workdps(50):
+        for a, b, c in [(0.5, 0.5, 1.0), (1.0, 1.0, 2.0), (2.0, 3.0, 4.0), (1.5, 2.5, 6.0), (-0.5, 0.5, 1.0), (3.5, 2.5, 2.0), (1.2, -0.7, -1.5)]:
+            for xi, g in zip(near_one, _hyp(sf, "2F1", (a, b, c), near_one)):
+                want = mp.hyp2f1(a, b, c, mp.mpf(float(xi)))
+                assert abs(float((mp.mpf(float(g)) - want) / want)) < 1e-12, (a, b, c, xi, g, float(want))
+    # nearly but not exactly an integer, next to x = 1: declined, not guessed
+    assert np.isnan(_hyp(sf, "2F1", (1.0, 1.0, 2.0 + 1e-7), np.array([0.9999])))[0]
 
 
 def test_hypergeometric_model_on_host_twin_against_mpmath():
