@@ -368,11 +368,16 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
                                   nullptr));
   } else {
     const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
-    const size_t gy = (row_count + m->info.tile_rows - 1) / m->info.tile_rows;
-    if (gy > 65535 || gx > 0x7fffffffULL)
-      return fail(INFLX_ERR_SHAPE, "grid too large for one launch (%zu x %zu tiles); sweep fewer rows per call", gx, gy);
+    if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch (%zu column tiles)", gx);
+    if (row_count > 0xffffffffULL) return fail(INFLX_ERR_SHAPE, "at most 2^32 grid rows per call (got %zu)", row_count);
     hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
-    HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+    // grid.y is limited to 65535 tiles: taller slabs take several launches, each told its first slab row
+    const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
+    for (size_t r0 = 0; r0 < row_count; r0 += rows_per_launch) {
+      a.stream_row0 = (uint32_t)r0;
+      const size_t gy = (std::min(rows_per_launch, row_count - r0) + m->info.tile_rows - 1) / m->info.tile_rows;
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+    }
   }
   return INFLX_OK;
 }

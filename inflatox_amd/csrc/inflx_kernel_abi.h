@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 10u
+#define INFLX_KERNEL_ABI 11u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -39,7 +39,7 @@ struct InflxSweepArgs {
   uint32_t P;
   uint32_t layout;      // InflxLayout
   uint32_t col_chunks;  // row kernels: number of column chunks a row is split into
-  uint32_t stream_row0; // inflx_sweep_rowstream6: slab row that blockIdx.y == 0 writes (launches cover <= 65535 rows)
+  uint32_t stream_row0; // slab row that blockIdx.y == 0 works on (store-stream and tile kernels: grid.y <= 65535 per launch)
   // row-broadcast path: per-row results, [P][row_count][table_replicas][8] doubles (first K of 8 used).
   // Every row's 64-byte entry is stored table_replicas times, on cache lines of its own, because the
   // ~400 wavefronts that stream one grid row all fetch it with scalar loads at the same moment: served

@@ -239,7 +239,8 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   double C[kNC];
   inflx_stage_col(x1, A, U, C);
 
-  const uint64_t row0 = (uint64_t)blockIdx.y * kTileRows;  // relative to row_begin
+  // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
+  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * kTileRows;
   const uint64_t left = a.row_count - row0;
   const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
   if ((int)tid < nrows) {

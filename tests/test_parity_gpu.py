@@ -622,6 +622,8 @@ def test_geometry_fuzz_sweeps_equal_point_evaluation(name, gpu_lib):
         ("doc", 70, 30011, 2, "complete", "aos"),  # tile path, ragged last column tile
         ("doc", 9000, 130, 1, "raw", "soa"),
         ("d5", 1500, 700, 2, "complete", "aos"),
+        ("doc", 2100001, 3, 1, "complete", "aos"),  # more than 65535 tiles of 32 rows: the tile path takes two launches
+        ("doc", 2097153, 2, 1, "raw", "soa"),
     ],
 )
 def test_large_geometries_equal_point_evaluation(name, n0, n1, P, op_name, layout_name, gpu_lib):
@@ -639,8 +641,9 @@ def test_large_geometries_equal_point_evaluation(name, n0, n1, P, op_name, layou
         got = np.moveaxis(got, 1, -1)
     # a seeded sample of points plus the corners and the seams of the launch limits
     rng = np.random.default_rng(n0 * 31 + n1)
-    ii = np.concatenate([rng.integers(0, n0, 4000), [0, n0 - 1, min(65534, n0 - 1), min(65535, n0 - 1), min(65536, n0 - 1)]])
-    jj = np.concatenate([rng.integers(0, n1, 4000), [0, n1 - 1, n1 // 2, min(255, n1 - 1), min(256, n1 - 1)]])
+    seam = 65535 * 32  # first row of the second tile launch
+    ii = np.concatenate([rng.integers(0, n0, 4000), [0, n0 - 1, min(65534, n0 - 1), min(65535, n0 - 1), min(65536, n0 - 1), min(seam - 1, n0 - 1), min(seam, n0 - 1), min(seam + 1, n0 - 1)]])
+    jj = np.concatenate([rng.integers(0, n1, 4000), [0, n1 - 1, n1 // 2, min(255, n1 - 1), min(256, n1 - 1), 0, n1 - 1, n1 // 2]])
     dx0, dx1 = (x0b - x0a) / n0, (x1b - x1a) / n1
     pts = np.column_stack([ii.astype(np.float64) * dx0 + x0a, jj.astype(np.float64) * dx1 + x1a])
     for q in range(P):
