@@ -746,3 +746,22 @@ def test_concurrent_sweeps_from_two_threads(gpu_lib):
     assert not errors, errors
     for g, w in zip(got, want):
         assert np.array_equal(g, w, equal_nan=True)
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_empty_inputs_are_no_ops(name, gpu_lib):
+    """Zero-size grids and trajectories: the reference's loops simply do not run (an (0, N, 6) array is a valid
+    C-contiguous numpy array); no launch, no error, empty results of the right shape."""
+    spec, art, lib = devlib(name, gpu_lib)
+    al = generalised_al(art)
+    for n0, n1 in ((0, 7), (7, 0), (0, 0)):
+        six = al.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False)
+        assert len(six) == 6 and all(a.shape == (n0, n1) for a in six)
+        assert al.consistency(spec.args, *spec.extent, n0, n1, progress=False).shape == (n0, n1)
+        assert al.flag_quantum_dif(spec.args, *spec.extent, n0, n1, progress=False).shape == (n0, n1)
+        assert lib.sweep_host(gpu_lib.OP_RAW, spec.args, np.array(spec.extent).reshape(2, 2), n0, n1, layout=gpu_lib.LAYOUT_SOA).shape == (5, n0, n1)
+    out = al.complete_analysis_ot(spec.args, np.zeros((0, 2)), progress=False)
+    assert len(out) == 6 and all(a.shape == (0, 1) for a in out)
+    assert al.epsilon_v_ot(spec.args, np.zeros((0, 2)), progress=False).shape == (0,)
+    stats = lib.sweep_stats(spec.args, np.array(spec.extent).reshape(2, 2), 0, 9)
+    assert (stats["count"] == 0).all()
