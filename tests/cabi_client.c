@@ -1,0 +1,67 @@
+/* A plain C client of the drop-in boundary (include/inflx_hip.h) -- TEST INFRASTRUCTURE.
+ * What a Rust/C maintainer of the reference would write: open an artefact, call the reference-shaped entry
+ * points, read the error text on failure.  No Python, no torch in this process.
+ *   usage: cabi_client ARTEFACT N0 N1 x0a x0b x1a x1b OUT.bin p0 [p1 ...]
+ * writes N0*N1*6 doubles (complete_analysis) followed by N0*N1 doubles (consistency_only) to OUT.bin. */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "inflx_hip.h"
+
+int main(int argc, char** argv) {
+  if (argc < 10) {
+    fprintf(stderr, "usage: %s ARTEFACT N0 N1 x0a x0b x1a x1b OUT.bin p0 [p1 ...]\n", argv[0]);
+    return 64;
+  }
+  const size_t n0 = (size_t)atol(argv[2]), n1 = (size_t)atol(argv[3]);
+  const double start_stop[4] = {atof(argv[4]), atof(argv[5]), atof(argv[6]), atof(argv[7])};
+  const size_t n_p = (size_t)(argc - 9);
+  double* p = malloc(n_p * sizeof(double));
+  for (size_t k = 0; k < n_p; ++k) p[k] = atof(argv[9 + k]);
+
+  int ndev = 0;
+  if (inflx_device_count(&ndev) != INFLX_OK || ndev < 1) {
+    fprintf(stderr, "no device: %s\n", inflx_last_error());
+    return 2;
+  }
+  inflx_model* model = NULL;
+  int rc = inflx_open(argv[1], 0, &model);
+  if (rc != INFLX_OK) {
+    fprintf(stderr, "inflx_open failed (%d): %s\n", rc, inflx_last_error());
+    return 3;
+  }
+  if (inflx_n_fields(model) != 2 || inflx_n_parameters(model) != n_p) {
+    fprintf(stderr, "model %s: %u fields, %u parameters (got %zu)\n", inflx_model_name(model), inflx_n_fields(model), inflx_n_parameters(model), n_p);
+    return 4;
+  }
+  /* a wrong parameter count must be refused with the shape status, and leave the handle usable */
+  double* six = calloc(n0 * n1 * 6, sizeof(double));
+  rc = inflx_complete_analysis(model, p, n_p + 1, six, start_stop, n0, n1, 0, 0);
+  if (rc != INFLX_ERR_SHAPE) {
+    fprintf(stderr, "expected INFLX_ERR_SHAPE for a wrong parameter count, got %d\n", rc);
+    return 5;
+  }
+  rc = inflx_complete_analysis(model, p, n_p, six, start_stop, n0, n1, 0, 0);
+  if (rc != INFLX_OK) {
+    fprintf(stderr, "inflx_complete_analysis failed (%d): %s\n", rc, inflx_last_error());
+    return 6;
+  }
+  double* one = calloc(n0 * n1, sizeof(double));
+  rc = inflx_consistency_only(model, p, n_p, one, start_stop, n0, n1, 0, 0);
+  if (rc != INFLX_OK) {
+    fprintf(stderr, "inflx_consistency_only failed (%d): %s\n", rc, inflx_last_error());
+    return 7;
+  }
+  FILE* f = fopen(argv[8], "wb");
+  if (!f) return 8;
+  fwrite(six, sizeof(double), n0 * n1 * 6, f);
+  fwrite(one, sizeof(double), n0 * n1, f);
+  fclose(f);
+  inflx_close(model);
+  free(six);
+  free(one);
+  free(p);
+  printf("ok %s\n", argv[1]);
+  return 0;
+}

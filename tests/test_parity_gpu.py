@@ -6,6 +6,8 @@ README hyperbolic model (the model north_star states the 1e-10 bar for) the plai
 1e-10 bound is asserted as well, with no allowance.
 """
 
+import os
+
 import numpy as np
 import pytest
 import tolerance as tol
@@ -765,3 +767,35 @@ def test_empty_inputs_are_no_ops(name, gpu_lib):
     assert al.epsilon_v_ot(spec.args, np.zeros((0, 2)), progress=False).shape == (0,)
     stats = lib.sweep_stats(spec.args, np.array(spec.extent).reshape(2, 2), 0, 9)
     assert (stats["count"] == 0).all()
+
+
+def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
+    """The drop-in boundary used from C alone (tests/cabi_client.c, linked against libinflx_hip.so): no Python and
+    no torch in that process; results equal the ctypes path bit for bit, a shape error comes back as its status."""
+    import subprocess
+
+    from inflatox_amd import _native, workloads
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "cabi_client"
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(
+        ["gcc", "-O1", "-std=c11", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}", os.path.join(root, "tests", "cabi_client.c"), f"-L{libdir}", "-linflx_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+        check=True,
+    )
+    spec, art, lib = devlib("doc", gpu_lib)
+    n0, n1 = 64, 48
+    out = tmp_path / "out.bin"
+    cmd = [str(exe), art.shared_object_path, str(n0), str(n1), *[repr(float(v)) for v in spec.extent], str(out), *[repr(float(v)) for v in spec.args]]
+    proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
+    data = np.fromfile(out, dtype=np.float64)
+    six, one = data[: n0 * n1 * 6].reshape(n0, n1, 6), data[n0 * n1 * 6 :].reshape(n0, n1)
+    ss = np.array(spec.extent).reshape(2, 2)
+    assert np.array_equal(six, lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ss, n0, n1), equal_nan=True)
+    assert np.array_equal(one, lib.sweep_host(gpu_lib.OP_CONSISTENCY, spec.args, ss, n0, n1), equal_nan=True)
+    # an artefact that is not a code object is an IO error for the C client too
+    bogus = tmp_path / "bogus.hsaco"
+    bogus.write_bytes(b"not a code object")
+    proc = subprocess.run([str(exe), str(bogus), "4", "4", "0", "1", "0", "1", str(out), "1.0"], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 3 and "inflx_open failed (1)" in proc.stderr
