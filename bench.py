@@ -4,24 +4,34 @@
   python bench.py [--gpus N --steps K --warmup W]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
+Both forms work for N > 1: started plainly (no WORLD_SIZE in the environment) the script launches
+`torch.distributed.run` itself -- before anything has touched the GPU -- and passes the one JSON line through.
+
 A "step" is one pass of the hot path: ONE complete_analysis sweep of the BASELINE configs[1]
 workload -- README hyperbolic model, args [m, phi0, L] = [1, 1, 1], extent (-1, 1, -1, 1),
 8192 x 8192 field grid, six f64 per point (48 B) written to a device-resident (N0, N1, 6) array.
 Multi-GPU (weak scaling, BASELINE configs[4] style): the outer *parameter* axis is sharded, every
 rank sweeps the full grid for its own parameter row (L differs per rank); results stay on the
 rank's GPU (no data-path collective: the rows are independent; the only collectives are the timing
-barrier and the MAX over ranks).
+barrier, the MAX over ranks and the gather of the per-rank kernel times for the report).
 
 Timed region: inputs (parameters, code object) resident on the device, result left in HBM.
 PyTorch provides the device buffer, the stream and torch.distributed only; every launch goes
 through the C ABI (libinflx_hip.so).
+
+After the timed region (N = 1 only, never part of `value`): `secondary` = BASELINE configs[2] (D5 4096^2 x 32
+parameter rows in one call) and configs[3] (EGNO 4096^2) timed with HIP events, `end_to_end` = the front-end call
+GeneralisedAL.complete_analysis(8192^2) -> six numpy arrays (PCIe-inclusive), `cpu_baseline` = the oracle on the
+host cores.
 """
 
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -29,7 +39,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full rate (78.6 TFLOP/s = 2 flop x this)
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
+PROFILE_ROUNDS = ("02", "01")  # profiles/rNN_traffic.json, rNN_valu.json: newest first
 
 
 def host_threads() -> int:
@@ -45,17 +57,23 @@ def host_threads() -> int:
     return n
 
 
-def recorded_traffic(kernel: str, model: str, n: int):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/), or None when
-    no measurement of this exact workload is on record."""
-    path = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    try:
-        rec = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if rec.get("workload", "").startswith(f"{model} {n}x{n} ") and kernel in rec:
-        return rec[kernel]["traffic_bytes"]
-    return None
+def code_object_id(path: str) -> str:
+    """What identifies the kernels a profile was taken of: the first 16 hex digits of the code object's SHA-256."""
+    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+
+
+def recorded(kind: str, key: str, code_id: str):
+    """The record `key` of the newest profiles/rNN_<kind>.json whose stamp (`code_objects[key]`) is the code
+    object that is loaded now; None when the kernels have changed since the counters were collected (a stale
+    number is worse than none) or nothing is on record."""
+    for rnd in PROFILE_ROUNDS:
+        try:
+            rec = json.load(open(os.path.join(ROOT, "profiles", f"r{rnd}_{kind}.json")))
+        except (OSError, ValueError):
+            continue
+        if rec.get("code_objects", {}).get(key) == code_id and key in rec:
+            return rec[key], f"profiles/r{rnd}_{kind}.json"
+    return None, None
 
 
 def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
@@ -92,6 +110,93 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     }
 
 
+def self_launch(opt) -> int:
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run as a child
+    (this process has not imported torch, let alone touched a GPU) and hand its exit code on."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]  # fmt: skip
+    return subprocess.run(cmd, env=env).returncode
+
+
+def secondary_workloads(_native, workloads, torch, np, device, stream):
+    """BASELINE configs[2] and [3] on this GPU, kernel time by HIP events on the launch stream (no part of `value`).
+    These are FP64-VALU-bound: the roofline that prices them is the VALU issue rate, from
+    the SQ instruction counters on record for exactly this code object; the HBM fraction is given beside it."""
+    out = []
+    cases = [
+        ("d5", 4096, 32, 3, "D5-brane model, 4096x4096 field grid x 32 parameter rows (a1 in linspace(2.5e-4, 1e-3, 32)) in ONE call, 25.8 GB device-resident"),
+        ("egno", 4096, 1, 30, "EGNO supergravity model, 4096x4096 field grid"),
+        ("doc", 4096, 1, 30, "documentation model (reference tests/test_doc.py), 4096x4096 field grid"),
+    ]
+    for name, n, P, repeats, text in cases:
+        try:
+            spec, art = workloads.artifact_for(name)
+            lib = _native.InflatoxDevLib(art.shared_object_path, device=device)
+            rows = np.tile(np.asarray(spec.args, dtype=np.float64), (P, 1))
+            if name == "d5" and P > 1:
+                rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)  # a1 (SURVEY.md section 8d, config C3)
+            buf = torch.empty((P, n, n, 6), dtype=torch.float64, device=f"cuda:{device}")
+            ms = lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats)
+            pps = P * n * n / (ms * 1e-3)
+            cid = code_object_id(art.shared_object_path)
+            valu, src = recorded("valu", name, cid)
+            rec = {
+                "workload": text,
+                "kernel": "inflx_sweep_tile_complete",
+                "ms": ms,
+                "repeats": repeats,
+                "points_per_s": pps,
+                "hbm_frac": BYTES_PER_POINT * pps / 1e9 / HBM_PEAK_GBPS,
+                "code_object": cid,
+                "roofline": None,
+            }
+            if valu:
+                ipp = valu["valu_insts_per_point"]
+                rec["roofline"] = {
+                    "bound": "valu",
+                    "achieved": pps * ipp / 1e12,
+                    "peak": FP64_LANE_RATE / 1e12,
+                    "unit": "T lane-instr/s (FP64 VALU, full-rate issue)",
+                    "frac": pps * ipp / FP64_LANE_RATE,
+                    "valu_insts_per_point": ipp,
+                    "source": src,
+                }
+            out.append(rec)
+            del buf, lib
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001 -- an extra must never break the benchmark line
+            out.append({"workload": text, "error": str(exc)[:300]})
+    return out
+
+
+def end_to_end(workloads, np, model: str, n: int, device: int):
+    """The front-end call a user of the reference makes: GeneralisedAL.complete_analysis -> six numpy arrays on
+    the host (device sweep + PCIe copy into a fresh np.zeros array), best of 3."""
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    spec, art = workloads.artifact_for(model)
+    al = GeneralisedAL(art, device=device)
+    best = float("inf")
+    for _ in range(3):
+        t0 = time.perf_counter()
+        res = al.complete_analysis(spec.args, *spec.extent, n, n, progress=False)
+        best = min(best, time.perf_counter() - t0)
+        del res
+    return {
+        "workload": f"GeneralisedAL.complete_analysis, {model} {n}x{n} -> six host numpy arrays (PCIe-inclusive)",
+        "ms": best * 1e3,
+        "points_per_s": n * n / best,
+        "GBps": BYTES_PER_POINT * n * n / best / 1e9,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,7 +205,13 @@ def main():
     ap.add_argument("--model", default="hyperbolic")
     ap.add_argument("--grid", dest="n", type=int, default=8192, help="grid points per axis")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads and the end-to-end call")
     opt = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and opt.gpus > 1:
+        raise SystemExit(self_launch(opt))
+    # must be in place before the first HIP call of this process (RCCL's IPC handles, see the Environment notes)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     import numpy as np
     import torch
@@ -124,7 +235,6 @@ def main():
     if distributed:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         # RCCL announces itself on stdout ("Librccl path : ..."); stdout carries the one JSON line only,
         # so point fd 1 at stderr while the process group comes up
         sys.stdout.flush()
@@ -200,6 +310,19 @@ def main():
     points = N0 * N1
     achieved = BYTES_PER_POINT * points / (ms_kernel * 1e-3) / 1e9
 
+    # every rank's own dominant-kernel time and roofline fraction, for the report of an N > 1 run
+    mine = torch.tensor([ms_kernel, ms_sweep, step_ms_events], dtype=torch.float64, device=comm_device)
+    if distributed:
+        gathered = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(gathered, mine)
+    else:
+        gathered = [mine]
+    per_rank = []
+    for r, g in enumerate(gathered):
+        k_ms, s_ms, e_ms = (float(v) for v in g.cpu())
+        gbps = BYTES_PER_POINT * points / (k_ms * 1e-3) / 1e9
+        per_rank.append({"rank": r, "kernel_ms": k_ms, "sweep_ms": s_ms, "step_ms_hip_events": e_ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS})
+
     # outside the timed region: the statistics path of a sharded sweep -- every rank reduces its own block
     # on the device (summary-only sweep), three six-element all-reduces combine the ranks (RCCL when N > 1)
     stats_info = None
@@ -220,6 +343,8 @@ def main():
 
     if rank == 0:
         kernel = "inflx_sweep_rowstream6" if row_path else "inflx_sweep_tile_complete"
+        cid = code_object_id(art.shared_object_path)
+        traffic_rec, traffic_src = recorded("traffic", kernel, cid) if (opt.model, opt.n) == ("hyperbolic", 8192) else (None, None)
         line = {
             "metric": "grid-points/sec on complete_analysis sweep; achieved HBM GB/s vs peak",
             "value": world * points * opt.steps / elapsed,
@@ -238,22 +363,40 @@ def main():
                 "parameter_rows_per_gpu": 1,
                 "parallelism": (f"parameter-axis x{world}" if world > 1 else "single GPU") + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearse else ""),
             },
+            "ranks": world,
+            "comm_backend": (dist.get_backend() if distributed else None),
+            "rccl_ranks": (dist.get_world_size() if distributed and backend == "nccl" else 0),
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBPS,
-                "traffic": recorded_traffic(kernel, opt.model, opt.n),
+                # HBM bytes per launch from the PMC passes on record for exactly this code object, else null
+                "traffic": traffic_rec["traffic_bytes"] if traffic_rec else None,
+                "traffic_source": traffic_src,
+                "code_object": cid,
                 "kernel": kernel,
                 "kernel_ms": ms_kernel,
                 "sweep_ms": ms_sweep,
                 "timed_region_ms_per_step_hip_events": step_ms_events,
                 "kernels_per_step": ["inflx_sweep_rowvals_complete", "inflx_sweep_rowstream6"] if row_path else ["inflx_sweep_tile_complete"],
                 "algorithmic_bytes_per_launch": BYTES_PER_POINT * points,
+                "per_rank": per_rank,
             },
         }
         line["summary_sweep"] = stats_info
+    if distributed:
+        dist.barrier()
+    if rank == 0:
+        if world == 1 and not opt.no_extras:
+            del out
+            torch.cuda.empty_cache()
+            line["secondary"] = secondary_workloads(_native, workloads, torch, np, local_rank, stream)
+            try:
+                line["end_to_end"] = end_to_end(workloads, np, opt.model, opt.n, local_rank)
+            except Exception as exc:  # noqa: BLE001
+                line["end_to_end"] = {"error": str(exc)[:300]}
         if world == 1 and not opt.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(opt.model, spec.args, spec.extent)
         print(json.dumps(line), flush=True)

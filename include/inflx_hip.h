@@ -133,10 +133,24 @@ int inflx_sweep_host(inflx_model* model, int op, const double* p, size_t P, size
  * P*row_count*N1*K*8 bytes on the model's device (`d_out_bytes` is checked); the kernel is
  * enqueued on `stream` (a hipStream_t; NULL = the model's own stream) and the call returns without
  * synchronising.  This is what the multi-GPU sharding and the benchmark use.
+ * `p` is copied into pinned memory owned by the model before the call returns: the caller may free or
+ * change it immediately, and consecutive calls with different parameters need no synchronisation.
  */
 int inflx_sweep_device(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
                        size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
                        size_t row_count, int layout, void* stream);
+
+/*
+ * Which kernels a sweep of this shape takes (introspection for tests and profiles; no launch):
+ *   plan[0] inflx_path; for INFLX_PATH_ROW_STREAM also plan[1] = parameter rows per row-table batch,
+ *   plan[2] = number of batches the call is cut into, plan[3] = replicas of a row's table entry.
+ */
+typedef enum inflx_path {
+  INFLX_PATH_TILE = 0,       /* inflx_sweep_tile_*: some model value depends on x[1]                    */
+  INFLX_PATH_ROW_STREAM = 1, /* inflx_sweep_rowvals_* + inflx_sweep_rowstream6/_planes (row-only model) */
+  INFLX_PATH_ROWS = 2        /* inflx_sweep_rows_*: row-only model, result shape the streams do not cover */
+} inflx_path;
+int inflx_sweep_plan(const inflx_model* model, int op, size_t P, size_t N1, size_t row_count, int layout, uint32_t plan[4]);
 
 /* As inflx_sweep_device, `repeats` times back to back between two HIP events recorded on the
  * launch stream; returns the mean duration of one sweep in milliseconds (synchronises).  A sweep of a

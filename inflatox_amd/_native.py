@@ -57,6 +57,7 @@ SIGNATURES = {
         [C.c_void_p, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_void_p, C.c_void_p],
     ),
     "inflx_synchronize": (C.c_int, [C.c_void_p]),
+    "inflx_sweep_plan": (C.c_int, [C.c_void_p, C.c_int, _SIZE, _SIZE, _SIZE, C.c_int, C.POINTER(C.c_uint32)]),
     "inflx_basis_on_points": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _SIZE, _DP]),
     "inflx_validate_basis_at_random": (C.c_int, [C.c_void_p, C.c_uint64]),
     "inflx_validate_basis_on_domain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _SIZE, _DP, _SIZE, _DP, C.c_double]),
@@ -350,6 +351,12 @@ class InflatoxDevLib:
             )
         )
         return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
+
+    def sweep_plan(self, op, P, N1, row_count, layout=LAYOUT_AOS) -> dict:
+        """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows", "batch_rows", "batches", "replicas"}``."""
+        plan = (C.c_uint32 * 4)()
+        _check(self._lib.inflx_sweep_plan(self._h, op, P, N1, row_count, layout, plan))
+        return {"path": ("tile", "row_stream", "rows")[plan[0]], "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))

@@ -89,6 +89,11 @@ unsigned prefault_threads() {
 // atomic matters: helper threads may still be walking a buffer the DMA engine has started to fill, and a
 // plain read-then-write could put a stale byte back over a freshly copied one; a locked read-modify-write
 // holds the cache line for its duration, so a coherent DMA write lands entirely before or after it.
+#if defined(__x86_64__)
+constexpr bool kTouchIsAtomic = true;
+#else
+constexpr bool kTouchIsAtomic = false;  // the fallbacks below may read-then-write: never concurrently with the DMA
+#endif
 void touch_range(char* begin, size_t bytes) {
   const size_t page = (size_t)sysconf(_SC_PAGESIZE);
   char* lo = reinterpret_cast<char*>((reinterpret_cast<uintptr_t>(begin) + page - 1) / page * page);
@@ -186,10 +191,22 @@ struct inflx_model {
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
   std::string name, path;
-  double* d_params = nullptr;
-  size_t d_params_cap = 0;
-  std::vector<double> params_on_device;  // what d_params currently holds (skips redundant uploads)
-  hipStream_t params_stream = nullptr;   // stream the last upload was ordered on
+  // Parameter rows travel through a small ring of (pinned host, device) buffer pairs: the caller's array is
+  // copied into pinned memory before the call returns (so its lifetime ends with the call, whatever kind
+  // of memory it is), the upload is a true asynchronous copy, and a slot is only overwritten once the
+  // kernels that read it have finished (`last_use`) -- back-to-back sweeps with different parameters on
+  // different streams never wait for each other on the host.
+  struct ParamSlot {
+    double* host = nullptr;         // pinned; always holds what `dev` holds (or will hold once the copy ran)
+    double* dev = nullptr;
+    size_t cap = 0, count = 0;      // doubles
+    hipStream_t stream = nullptr;   // stream the upload was ordered on
+    hipEvent_t last_use = nullptr;  // recorded behind the last kernel that reads `dev`
+    bool in_flight = false;
+  };
+  static constexpr int kParamSlots = 4;
+  ParamSlot pslot[kParamSlots];
+  int pcur = 0;
   void* d_chunk[2] = {nullptr, nullptr};
   size_t d_chunk_cap[2] = {0, 0};
   void* d_whole = nullptr;  // whole-result buffer of the host path (results up to whole_result_limit())
@@ -214,27 +231,46 @@ int read_global(inflx_model* m, const char* sym, T* dst, size_t bytes, bool exac
   return INFLX_OK;
 }
 
-int ensure_params(inflx_model* m, const double* p, size_t count, hipStream_t s) {
-  if (count > m->d_params_cap) {
-    if (m->d_params) HIP_TRY(hipFree(m->d_params));
-    m->d_params = nullptr;
-    m->params_on_device.clear();
-    size_t cap = std::max<size_t>(count, 64);
-    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_params), cap * sizeof(double)));
-    m->d_params_cap = cap;
-  }
-  // a parameter sweep re-launches with the same rows far more often than it changes them; the upload
-  // (a synchronous staging copy for pageable memory) is skipped when the device copy is current and
-  // was last written on the same stream ordering domain (same stream)
-  if (m->params_on_device.size() == count && m->params_stream == s &&
-      memcmp(m->params_on_device.data(), p, count * sizeof(double)) == 0)
+// Put `count` doubles of parameters where kernels enqueued on `s` can read them; *d_params is the device
+// address.  A sweep re-launches with the same rows far more often than it changes them: when the current
+// slot already holds these values for this stream nothing is uploaded.
+int acquire_params(inflx_model* m, const double* p, size_t count, hipStream_t s, const double** d_params) {
+  inflx_model::ParamSlot& cur = m->pslot[m->pcur];
+  if (cur.dev && cur.count == count && cur.stream == s && memcmp(cur.host, p, count * sizeof(double)) == 0) {
+    *d_params = cur.dev;
     return INFLX_OK;
-  // the kernels that read d_params run on the stream of the upload before them; when that stream
-  // changes, let the old one finish before its parameters are overwritten
-  if (m->params_stream && m->params_stream != s) HIP_TRY(hipStreamSynchronize(m->params_stream));
-  HIP_TRY(hipMemcpyAsync(m->d_params, p, count * sizeof(double), hipMemcpyHostToDevice, s));
-  m->params_on_device.assign(p, p + count);
-  m->params_stream = s;
+  }
+  const int next = (m->pcur + 1) % inflx_model::kParamSlots;
+  inflx_model::ParamSlot& slot = m->pslot[next];
+  if (slot.in_flight) {
+    HIP_TRY(hipEventSynchronize(slot.last_use));  // four sweeps ago: long finished unless the queue is that deep
+    slot.in_flight = false;
+  }
+  if (!slot.last_use) HIP_TRY(hipEventCreateWithFlags(&slot.last_use, hipEventDisableTiming));
+  if (count > slot.cap) {
+    if (slot.dev) HIP_TRY(hipFree(slot.dev));
+    if (slot.host) HIP_TRY(hipHostFree(slot.host));
+    slot.dev = slot.host = nullptr;
+    slot.cap = slot.count = 0;
+    const size_t cap = std::max<size_t>(count, 64);
+    HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&slot.host), cap * sizeof(double), hipHostMallocDefault));
+    HIP_TRY(hipMalloc(reinterpret_cast<void**>(&slot.dev), cap * sizeof(double)));
+    slot.cap = cap;
+  }
+  memcpy(slot.host, p, count * sizeof(double));
+  HIP_TRY(hipMemcpyAsync(slot.dev, slot.host, count * sizeof(double), hipMemcpyHostToDevice, s));
+  slot.count = count;
+  slot.stream = s;
+  m->pcur = next;
+  *d_params = slot.dev;
+  return INFLX_OK;
+}
+
+// every kernel that reads the current parameter slot has been enqueued, the last of them on `reader`
+int release_params(inflx_model* m, hipStream_t reader) {
+  inflx_model::ParamSlot& cur = m->pslot[m->pcur];
+  HIP_TRY(hipEventRecord(cur.last_use, reader));
+  cur.in_flight = true;
   return INFLX_OK;
 }
 
@@ -272,6 +308,30 @@ bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   return aos6 || planes;
 }
 
+// Geometry of the two-launch row-broadcast path for one call (shared by launch_grid and inflx_sweep_plan).
+struct RowStreamPlan {
+  size_t cpr;       // workgroups (4 KiB pieces) per grid row
+  size_t replicas;  // copies of every row's table entry, a power of two
+  size_t batch;     // parameter rows per table batch
+};
+RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P, size_t N1, size_t row_count) {
+  const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
+  const size_t units_row = aos6 ? 3 * N1 : N1 / 2;
+  RowStreamPlan r;
+  r.cpr = (units_row + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
+  // replicas of every row's table entry (see inflx_kernel_abi.h); a power of two (the evaluation
+  // kernel indexes with shifts), fewer for short rows
+  r.replicas = 32;
+  while (r.replicas > 1 && r.replicas > r.cpr) r.replicas /= 2;
+  // The table has to stay in the 256 MiB Infinity Cache between its evaluation and its use (a table
+  // fetch from HBM throttles the store stream from 6.6 to 5.0 TB/s, measured at P = 16): parameter
+  // rows are processed in batches whose table is at most 64 MiB, each batch = evaluation + stream,
+  // and the double-buffered side stream overlaps the evaluation of batch k+1 with the stream of batch k.
+  const size_t line_bytes = row_count * r.replicas * 64;
+  r.batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(line_bytes, 1)));
+  return r;
+}
+
 // Enqueue one sweep on `s`; `d_params` points at P parameter rows in device memory.
 // `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
 // 2 = only the store stream (used to time the dominant kernel on its own).
@@ -304,20 +364,14 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   if (takes_row_stream(m, op, layout, P, N1)) {
     // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
     // store per thread, 4 KiB per workgroup); `what` selects both (0), or one of them for timing
-    const size_t units_row = aos6 ? 3 * N1 : N1 / 2;
-    const size_t cpr = (units_row + m->info.row_chunk_units - 1) / m->info.row_chunk_units;
+    const RowStreamPlan plan = row_stream_plan(m, op, layout, P, N1, row_count);
+    const size_t cpr = plan.cpr, replicas = plan.replicas, batch = plan.batch;
     if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
-    // replicas of every row's table entry (see inflx_kernel_abi.h); a power of two (the evaluation
-    // kernel indexes with shifts), fewer for short rows
-    size_t replicas = 32;
-    while (replicas > 1 && replicas > cpr) replicas /= 2;
-    // The table has to stay in the 256 MiB Infinity Cache between its evaluation and its use (a table
-    // fetch from HBM throttles the store stream from 6.6 to 5.0 TB/s, measured at P = 16): parameter
-    // rows are processed in batches whose table is at most 64 MiB, each batch = evaluation + stream,
-    // and the double-buffered side stream overlaps the evaluation of batch k+1 with the stream of batch k.
-    const size_t line_bytes = row_count * replicas * 64;
-    const size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(line_bytes, 1)));
     const size_t K = kOpWidth[op];
+    // the timing-only mode re-runs store streams from the table of the sweep before it, and only the last
+    // batch's table is still there
+    if (what == 2 && batch < P)
+      return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
     for (size_t p0 = 0; p0 < P; p0 += batch) {
       const size_t pb = std::min(batch, P - p0);
       // `what` == 2 (timing only) re-runs the store streams from whatever the tables hold
@@ -624,7 +678,11 @@ void inflx_close(inflx_model* m) {
   }
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
-  if (m->d_params) (void)hipFree(m->d_params);
+  for (auto& slot : m->pslot) {
+    if (slot.dev) (void)hipFree(slot.dev);
+    if (slot.host) (void)hipHostFree(slot.host);
+    if (slot.last_use) (void)hipEventDestroy(slot.last_use);
+  }
   if (m->d_stats) (void)hipFree(m->d_stats);
   if (m->d_whole) (void)hipFree(m->d_whole);
   if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -645,6 +703,24 @@ int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t*
   if (nr) *nr = m->info.n_row;
   if (nc) *nc = m->info.n_col;
   if (out_mask) *out_mask = m->info.out_mask;
+  return INFLX_OK;
+}
+
+int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t row_count, int layout, uint32_t plan[4]) {
+  if (!m || !plan) return fail(INFLX_ERR_ARG, "model handle / plan array is NULL");
+  if (op < 0 || op >= INFLX_OP_COUNT) return fail(INFLX_ERR_ARG, "unknown sweep operation %d", op);
+  plan[0] = plan[1] = plan[2] = plan[3] = 0;
+  if (takes_row_stream(m, op, layout, P, N1)) {
+    const RowStreamPlan r = row_stream_plan(m, op, layout, P, N1, row_count);
+    plan[0] = INFLX_PATH_ROW_STREAM;
+    plan[1] = (uint32_t)r.batch;
+    plan[2] = (uint32_t)((P + r.batch - 1) / r.batch);
+    plan[3] = (uint32_t)r.replicas;
+  } else if ((m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF) {
+    plan[0] = INFLX_PATH_ROWS;
+  } else {
+    plan[0] = INFLX_PATH_TILE;
+  }
   return INFLX_OK;
 }
 
@@ -670,11 +746,13 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
   }
   static_assert(sizeof(inflx_summary) == 18 * 8, "inflx_summary must match the device layout");
   HIP_TRY(hipMemcpyAsync(m->d_stats, &init, sizeof init, hipMemcpyHostToDevice, eval));
-  if ((rc = ensure_params(m, p, P * n_p, eval))) return rc;
+  const double* d_params = nullptr;
+  if ((rc = acquire_params(m, p, P * n_p, eval, &d_params))) return rc;
   if (row_count && N1) {
-    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, INFLX_AOS, s, 0, 0.0, m->d_stats);
+    rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, INFLX_AOS, s, 0, 0.0, m->d_stats);
     if (rc) return rc;
   }
+  if ((rc = release_params(m, eval))) return rc;
   HIP_TRY(hipMemcpyAsync(summary, m->d_stats, sizeof *summary, hipMemcpyDeviceToHost, eval));
   HIP_TRY(hipStreamSynchronize(eval));
   if (eval != s) HIP_TRY(hipStreamSynchronize(s));
@@ -703,8 +781,11 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
   // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
   // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
-  if ((rc = ensure_params(m, p, P * n_p, takes_row_stream(m, op, layout, P, N1) ? m->side : s))) return rc;
-  return launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
+  hipStream_t reader = takes_row_stream(m, op, layout, P, N1) ? m->side : s;
+  const double* d_params = nullptr;
+  if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
+  if ((rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s))) return rc;
+  return release_params(m, reader);
 }
 
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
@@ -715,14 +796,17 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
   if (rc) return rc;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+  hipStream_t reader = takes_row_stream(m, op, layout, P, N1) ? m->side : s;
+  const double* d_params = m->pslot[m->pcur].dev;  // what the call above uploaded (or found in place)
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipEventRecord(m->t0, s));
   for (int k = 0; k < repeats; ++k) {
-    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s,
+    rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s,
                      dominant_only ? 2 : 0);
     if (rc) return rc;
   }
   HIP_TRY(hipEventRecord(m->t1, s));
+  if ((rc = release_params(m, reader))) return rc;
   HIP_TRY(hipEventSynchronize(m->t1));
   float ms = 0.f;
   HIP_TRY(hipEventElapsedTime(&ms, m->t0, m->t1));
@@ -739,12 +823,13 @@ int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const dou
   const size_t in_bytes = n * 2 * sizeof(double), out_bytes = n * 7 * sizeof(double);
   if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
   if ((rc = ensure_chunk(m, 1, in_bytes))) return rc;
-  if ((rc = ensure_params(m, p, n_p, m->stream))) return rc;
+  const double* d_params = nullptr;
+  if ((rc = acquire_params(m, p, n_p, m->stream, &d_params))) return rc;
   HIP_TRY(hipMemcpyAsync(m->d_chunk[1], x, in_bytes, hipMemcpyHostToDevice, m->stream));
   InflxTrajectoryArgs a;
   memset(&a, 0, sizeof a);
   a.out = static_cast<double*>(m->d_chunk[0]);
-  a.params = m->d_params;
+  a.params = d_params;
   a.points = static_cast<const double*>(m->d_chunk[1]);
   a.n = n;
   a.P = 1;
@@ -823,7 +908,6 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
   if (row_count == 0 || N1 == 0) return INFLX_OK;
   HIP_TRY(hipSetDevice(m->device));
-  if ((rc = ensure_params(m, p, P * n_p, takes_row_stream(m, op, layout, 1, N1) ? m->side : m->stream))) return rc;
 
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
@@ -841,15 +925,22 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       whole = false;
     }
   }
+  // the stream of the kernels that read the parameters: decided by the P the launches below really see (the
+  // whole-result path launches all P rows at once, the chunk pipeline one parameter row at a time)
+  hipStream_t reader = takes_row_stream(m, op, layout, whole ? P : 1, N1) ? m->side : m->stream;
+  const double* d_params = nullptr;
+  if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
   if (whole) {
     // One launch for everything, one copy for everything: the device buffer has the layout of `out`.
     // The destination pages are made resident by helper threads that run ahead of the copy: the first
     // stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the resident
     // frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
-    rc = launch_grid(m, op, m->d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
+    rc = launch_grid(m, op, d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
     if (rc) return rc;
     advise_huge_pages(out, total);
-    const size_t head = std::min<size_t>(total, size_t(64) << 20);
+    // helpers may only walk the destination while the copy is under way if their page touch is a real atomic
+    // read-modify-write (touch_range); elsewhere everything is made resident before the copy starts
+    const size_t head = kTouchIsAtomic ? std::min<size_t>(total, size_t(64) << 20) : total;
     prefault_range(out, head);
     std::vector<std::thread> pool;
     if (total > head) {
@@ -924,7 +1015,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     const int b = (int)(c & 1);
     // a chunk holds rows of a single parameter row: launch with P = 1 at that row's parameters
     if (used[b] && hipStreamWaitEvent(m->stream, m->copy_done[b], 0) != hipSuccess) { drain(); return fail(INFLX_ERR_DEVICE, "hipStreamWaitEvent failed"); }
-    rc = launch_grid(m, op, m->d_params + pc.pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + pc.r, pc.nrows, layout,
+    rc = launch_grid(m, op, d_params + pc.pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + pc.r, pc.nrows, layout,
                      m->stream, 0, accuracy);
     if (rc) { drain(); return rc; }
     if (ready.valid()) ready.wait();  // pages of this chunk's destination are resident
@@ -998,13 +1089,14 @@ int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_
   const size_t in_bytes = n * 2 * sizeof(double), out_bytes = n * K * sizeof(double);
   if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
   if ((rc = ensure_chunk(m, 1, in_bytes))) return rc;
-  if ((rc = ensure_params(m, p, n_p, m->stream))) return rc;
+  const double* d_params = nullptr;
+  if ((rc = acquire_params(m, p, n_p, m->stream, &d_params))) return rc;
   if (progress) say("Calculating on trajectory (%zu points) on HIP device %d.", n, m->device);
   HIP_TRY(hipMemcpyAsync(m->d_chunk[1], x, in_bytes, hipMemcpyHostToDevice, m->stream));
   InflxTrajectoryArgs a;
   memset(&a, 0, sizeof a);
   a.out = static_cast<double*>(m->d_chunk[0]);
-  a.params = m->d_params;
+  a.params = d_params;
   a.points = static_cast<const double*>(m->d_chunk[1]);
   a.n = n;
   a.P = 1;

@@ -23,7 +23,7 @@ def _line(proc):
 
 def test_single_gpu_line():
     proc = subprocess.run(
-        [sys.executable, "bench.py", "--grid", "2048", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=600
+        [sys.executable, "bench.py", "--grid", "2048", "--steps", "5", "--warmup", "2", "--no-cpu-baseline"], cwd=ROOT, capture_output=True, text=True, timeout=900
     )
     line = _line(proc)
     for key in REQUIRED:
@@ -34,6 +34,14 @@ def test_single_gpu_line():
     roof = line["roofline"]
     assert roof["bound"] == "hbm" and roof["unit"] == "GB/s" and abs(roof["frac"] - roof["achieved"] / roof["peak"]) < 1e-12
     assert "workload" in line["config"] and "model" not in line["config"]
+    assert roof["per_rank"][0]["rank"] == 0 and abs(roof["per_rank"][0]["kernel_ms"] - roof["kernel_ms"]) < 1e-9
+    assert line["rccl_ranks"] == 0 and line["ranks"] == 1
+    # BASELINE configs[2] and [3] and the PCIe-inclusive front-end call ride on the same line (never part of `value`)
+    sec = {rec["workload"].split(",")[0]: rec for rec in line["secondary"]}
+    assert all("error" not in rec for rec in line["secondary"]), line["secondary"]
+    assert sec["D5-brane model"]["points_per_s"] > 1e9 and sec["EGNO supergravity model"]["points_per_s"] > 1e9
+    assert "x 32 parameter rows" in sec["D5-brane model"]["workload"]
+    assert line["end_to_end"]["points_per_s"] > 1e8
 
 
 def _free_port():
@@ -44,12 +52,22 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def test_two_rank_rehearsal():
+@pytest.mark.parametrize("form", ["plain", "torchrun"])
+def test_two_rank_rehearsal(form):
+    """N > 1 both ways the driver may start it: `python bench.py --gpus 2` (the script launches its ranks itself,
+    before anything has touched the GPU) and under torch.distributed.run."""
     env = dict(os.environ, INFLX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-           "bench.py", "--gpus", "2", "--grid", "2048", "--steps", "5", "--warmup", "2"]  # fmt: skip
+    env.pop("WORLD_SIZE", None)
+    tail = ["bench.py", "--gpus", "2", "--grid", "2048", "--steps", "5", "--warmup", "2"]
+    if form == "plain":
+        cmd = [sys.executable, *tail]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), *tail]  # fmt: skip
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     line = _line(proc)
+    assert line["ranks"] == 2 and line["comm_backend"] == "gloo" and line["rccl_ranks"] == 0
+    assert [r["rank"] for r in line["roofline"]["per_rank"]] == [0, 1] and all(r["kernel_ms"] > 0 for r in line["roofline"]["per_rank"])
+    assert "secondary" not in line
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
     assert "REHEARSAL" in line["config"]["parallelism"]
     # both ranks' rows are counted: value = 2 * points * steps / max-over-ranks time

@@ -359,6 +359,69 @@ def test_d5_parameter_axis_sampled(gpu_lib):
         judge("d5", rows[k], pts, (1500,), raw, got, want, tol.epilogue, f"d5/P-row {k}")
 
 
+def test_config3_d5_4096_x_32_parameter_rows_in_one_call(gpu_lib):
+    """BASELINE configs[2] at full size: D5, 4096 x 4096 x P = 32 (a1 in linspace(2.5e-4, 1e-3, 32))
+    in ONE call, 25.8 GB device-resident; 1000 random grid points of every parameter row against the oracle
+    evaluated at exactly those points with exactly that row's parameters."""
+    import torch
+
+    spec, art, lib = devlib("d5", gpu_lib)
+    n, P = 4096, 32
+    rows = np.tile(spec.args, (P, 1))
+    rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)
+    torch.cuda.empty_cache()
+    out = torch.full((P, n, n, 6), -7.0, dtype=torch.float64, device="cuda:0")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    rng = np.random.default_rng(32)
+    om, _ = oracle_model("d5")
+    x0a, x0b, x1a, x1b = spec.extent
+    m = 1000
+    for k in range(P):
+        ii, jj = rng.integers(0, n, m), rng.integers(0, n, m)
+        pts = np.column_stack([ii * ((x0b - x0a) / n) + x0a, jj * ((x1b - x1a) / n) + x1a])
+        want = om.trajectory_sweep(OP.COMPLETE, rows[k], pts)
+        raw = om.trajectory_sweep(OP.RAW, rows[k], pts)
+        got = out[k][torch.as_tensor(ii, device="cuda:0"), torch.as_tensor(jj, device="cuda:0")].cpu().numpy()
+        judge("d5", rows[k], pts, (m,), raw, got, want, tol.epilogue, f"d5 4096^2 x 32, parameter row {k}")
+    # nothing was left unwritten, and neighbouring parameter rows differ
+    assert not bool((out == -7.0).any())
+    assert not bool(((out[0] == out[1]) | (torch.isnan(out[0]) & torch.isnan(out[1]))).all())
+    del out
+    torch.cuda.empty_cache()
+
+
+def test_config5_per_gpu_share_hyperbolic_8192_x_64(gpu_lib):
+    """The per-GPU share of BASELINE configs[4] (8192 x 8192 x 512 parameter rows over 8 GPUs): 64 parameter rows
+    (L in linspace(0.2, 2.0, 512)[:64]) in ONE call, 206 GB device-resident, 16 table batches.
+    Every column equals column 0; column 0 of every parameter row equals the oracle's 8192 x 1 sweep."""
+    import torch
+
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    n, P = 8192, 64
+    rows = np.tile(spec.args, (P, 1))
+    rows[:, 2] = np.linspace(0.2, 2.0, 512)[:P]
+    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n, n) == {"path": "row_stream", "batch_rows": 4, "batches": 16, "replicas": 32}
+    torch.cuda.empty_cache()
+    free, _ = torch.cuda.mem_get_info()
+    need = P * n * n * 48
+    if free < need + (8 << 30):
+        pytest.skip(f"needs {need / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} GiB available")
+    out = torch.empty((P, n, n, 6), dtype=torch.float64, device="cuda:0")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    om, _ = oracle_model("hyperbolic")
+    for k in range(P):
+        col0 = out[k, :, :1, :]
+        same = (out[k] == col0) | (torch.isnan(out[k]) & torch.isnan(col0))
+        assert bool(same.all()), k
+        del same
+        want = om.grid_sweep(OP.COMPLETE, rows[k], spec.extent, n, 1)[:, 0, :]
+        compare(col0[:, 0, :].cpu().numpy(), want, 1e-10, f"hyperbolic 8192^2 x 64, parameter row {k}")
+    del out
+    torch.cuda.empty_cache()
+
+
 def test_sharded_sweep_with_hip_compute(gpu_lib):
     """inflatox_amd.distributed on one GPU (world = 1): the plan owns everything, the block equals sweep_host."""
     from inflatox_amd.distributed import HipCompute, ShardedSweep, plan_shard
@@ -618,7 +681,7 @@ def test_geometry_fuzz_sweeps_equal_point_evaluation(name, gpu_lib):
     [
         ("hyperbolic", 70001, 48, 1, "complete", "aos"),  # more than 65535 rows: the store stream takes two launches
         ("hyperbolic", 66000, 40, 2, "consistency", "aos"),  # single-value planes over more than 65535 rows
-        ("hyperbolic", 3000, 640, 37, "complete", "aos"),  # a parameter batch: several table batches
+        ("hyperbolic", 3000, 640, 37, "complete", "aos"),  # a parameter batch (ONE table batch: 8 replicas x 3000 rows x 64 B x 37 = 57 MB; several batches: tests/test_row_table_gpu.py)
         ("hyperbolic", 900, 1201, 3, "raw", "soa"),  # odd row length, SoA: the fallback row kernel
         ("hyperbolic", 64, 40000, 2, "complete", "soa"),  # very long rows
         ("doc", 70, 30011, 2, "complete", "aos"),  # tile path, ragged last column tile
