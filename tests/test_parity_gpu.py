@@ -371,6 +371,7 @@ def test_config3_d5_4096_x_32_parameter_rows_in_one_call(gpu_lib):
     rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)
     torch.cuda.empty_cache()
     out = torch.full((P, n, n, 6), -7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()  # the fill ran on torch's default stream, the sweep runs on the model's own
     lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     rng = np.random.default_rng(32)

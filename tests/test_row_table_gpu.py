@@ -64,11 +64,13 @@ def test_three_table_batches_in_one_call(hyp, gpu_lib):
     import torch
 
     spec, lib = hyp
+    torch.cuda.empty_cache()
     n0, n1, P = 8192, 2731, 9
     plan = lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n1, n0)
     assert plan == {"path": "row_stream", "batch_rows": 4, "batches": 3, "replicas": 32}, plan
     rows = distinct_rows(P, 0)
     out = torch.full((P, n0, n1, 6), -7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()  # the fill ran on torch's default stream, the sweep runs on the model's own
     lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     check_block(out, rows, spec.extent, n0, "3 batches")
@@ -81,12 +83,14 @@ def test_many_small_batches_and_a_row_range(hyp, gpu_lib):
     import torch
 
     spec, lib = hyp
+    torch.cuda.empty_cache()
     n0, n1, P = 70000, 2731, 7
     rb, rc = 3000, 65536
     plan = lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n1, rc)
     assert plan["path"] == "row_stream" and plan["batch_rows"] == 1 and plan["batches"] == 7, plan
     rows = distinct_rows(P, 1)
     out = torch.full((P, rc, n1, 6), -7.0, dtype=torch.float64, device="cuda:0")  # 60 GB
+    torch.cuda.synchronize()
     lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, row_begin=rb, row_count=rc, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     om, _ = oracle_model("hyperbolic")
@@ -105,11 +109,13 @@ def test_plane_stream_batches(hyp, gpu_lib):
     import torch
 
     spec, lib = hyp
+    torch.cuda.empty_cache()
     n0, n1, P = 8192, 16384, 9
     plan = lib.sweep_plan(gpu_lib.OP_EPSILON_V, P, n1, n0)
     assert plan["path"] == "row_stream" and plan["batches"] == 3, plan
     rows = distinct_rows(P, 2)
     out = torch.full((P, n0, n1), -7.0, dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()  # the fill ran on torch's default stream, the sweep runs on the model's own
     lib.sweep_device(gpu_lib.OP_EPSILON_V, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     check_block(out, rows, spec.extent, n0, "epsilon_V planes", op=OP.EPSILON_V)
@@ -118,6 +124,7 @@ def test_plane_stream_batches(hyp, gpu_lib):
     assert lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n1, n0, layout=gpu_lib.LAYOUT_SOA)["batches"] == 2
     rows = distinct_rows(P, 3)
     soa = torch.full((P, 6, n0, n1), -7.0, dtype=torch.float64, device="cuda:0")  # 32 GB
+    torch.cuda.synchronize()
     lib.sweep_device(gpu_lib.OP_COMPLETE, rows, soa.data_ptr(), soa.numel() * 8, spec.extent, n0, n1, layout=gpu_lib.LAYOUT_SOA, stream=torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     om, _ = oracle_model("hyperbolic")
@@ -139,7 +146,9 @@ def test_back_to_back_calls_with_different_parameters(hyp, gpu_lib):
     import torch
 
     spec, lib = hyp
-    stream = torch.cuda.current_stream().cuda_stream
+    torch.cuda.empty_cache()
+    ts = torch.cuda.Stream(device="cuda:0")  # the -7 fills and the sweeps are enqueued on this one stream, in order
+    stream = ts.cuda_stream
     n0, n1 = 8192, 2731
     jobs = []  # (tensor, rows, kind, extra)
     scratch = np.empty((6, 3))
@@ -148,7 +157,8 @@ def test_back_to_back_calls_with_different_parameters(hyp, gpu_lib):
         rc = n0 if rc is None else rc
         rows = distinct_rows(P, salt)
         shape = (P, rc, n1, 6) if op == gpu_lib.OP_COMPLETE else (P, rc, n1)
-        out = torch.full(shape, -7.0, dtype=torch.float64, device="cuda:0")
+        with torch.cuda.stream(ts):
+            out = torch.full(shape, -7.0, dtype=torch.float64, device="cuda:0")
         buf = scratch[:P]
         buf[:] = rows
         lib.sweep_device(op, buf, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, row_begin=rb, row_count=rc, stream=stream)
@@ -160,7 +170,7 @@ def test_back_to_back_calls_with_different_parameters(hyp, gpu_lib):
     enqueue(1, 11)
     enqueue(6, 12)  # two table batches (4 + 2)
     enqueue(1, 13)
-    enqueue(2, 14, op=gpu_lib.OP_EPSILON_V, oop=OP.EPSILON_V)  # the plane stream in between
+    enqueue(2, 14, op=gpu_lib.OP_EPSILON_V, oop=OP.EPSILON_V)  # odd N1: the fallback row kernel, which reads its parameters on another stream
     enqueue(1, 15, rb=1000, rc=4096)
     enqueue(5, 16)
     enqueue(1, 17)
@@ -186,10 +196,12 @@ def test_back_to_back_tile_path_calls(gpu_lib):
 
     spec, art = workloads.artifact_for("doc")
     lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
-    stream = torch.cuda.current_stream().cuda_stream
+    ts = torch.cuda.Stream(device="cuda:0")
+    stream = ts.cuda_stream
     n0, n1 = 1500, 1300
     params = [spec.args * (1.0 + 0.07 * k) for k in range(6)]
-    outs = [torch.full((n0, n1, 6), -7.0, dtype=torch.float64, device="cuda:0") for _ in params]
+    with torch.cuda.stream(ts):
+        outs = [torch.full((n0, n1, 6), -7.0, dtype=torch.float64, device="cuda:0") for _ in params]
     buf = np.empty_like(spec.args)
     torch.cuda.synchronize()
     for p, out in zip(params, outs):
@@ -209,8 +221,10 @@ def test_dominant_only_timing_refuses_several_batches(hyp, gpu_lib):
     import torch
 
     spec, lib = hyp
+    torch.cuda.empty_cache()
     n0, n1, P = 8192, 2731, 5
     out = torch.empty((P, n0, n1, 6), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
     rows = distinct_rows(P, 20)
     with pytest.raises(ValueError):
         lib.sweep_device_timed(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream, repeats=2, dominant_only=True)
