@@ -253,6 +253,9 @@ class Compiler:
     print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
     """
 
+    #: `hoist_reciprocals=None` turns the hoisted-reciprocal division on when the five sweep values contain at least
+    #: this many per-point quotients by a denominator of an earlier stage
+    HOIST_MIN_QUOTIENTS = 6
     c_prefix = "inflx_auto_"
     lib_prefix = "libinflx_auto_"
 
@@ -289,7 +292,7 @@ class Compiler:
         staged: bool = True,
         exact_constants: bool = False,
         regroup: bool = False,
-        hoist_reciprocals: bool = False,
+        hoist_reciprocals: bool | None = None,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -387,19 +390,29 @@ class Compiler:
             def cse_vector(vector):
                 return sympy.cse(list(vector), symbols=self._cse_symbols(), list=True)
 
-        text, info = emit_stage_header(
-            self.symbolic_out,
-            params,
-            self.constants,
-            self.symbolic_out.model_name,
-            __version__,
-            __abi_version__,
-            staged=self.staged,
-            cse=cse,
-            cse_vector=cse_vector,
-            regroup=self.regroup,
-            hoist_reciprocals=self.hoist_reciprocals,
-        )
+        def emit(hoist):
+            return emit_stage_header(
+                self.symbolic_out,
+                params,
+                self.constants,
+                self.symbolic_out.model_name,
+                __version__,
+                __abi_version__,
+                staged=self.staged,
+                cse=cse,
+                cse_vector=cse_vector,
+                regroup=self.regroup,
+                hoist_reciprocals=hoist,
+            )
+
+        if self.hoist_reciprocals is None:
+            # automatic: the second copy of the point stage and the bookkeeping around it only pay when enough
+            # IEEE divisions leave the per-point stage (D5: 29 of 53; the documentation model: 1 of 16)
+            text, info = emit(self.staged)
+            if info["hoisted_quotients"] < self.HOIST_MIN_QUOTIENTS:
+                text, info = emit(False)
+        else:
+            text, info = emit(self.hoist_reciprocals)
         self.stage_info = info
         return text
 

@@ -51,32 +51,56 @@ INFLX_FN double inflx_hpow(double x) {
 
 // ---- division by a value that is known one stage earlier ---------------------------------------------
 // A quotient a/b whose denominator depends on fewer grid axes than its numerator is the single most
-// expensive thing left in the per-point stage: an IEEE double division is 13 instructions, several of them
-// at quarter rate (~72 cycles per wavefront).  With y = RN(1/b) computed once per row / column / sweep
-// (inflx_recip, an IEEE division itself), the per-point work is one multiplication and two FMAs:
+// expensive thing left in the per-point stage: an IEEE double division is 11 instructions, one of them
+// (v_rcp_f64) at a third of the full rate -- 13.0 times the issue cost of one v_fma_f64, measured
+// (scripts/micro/valu_rates.hip).  With y = RN(1/b) computed once per row / column / sweep (inflx_recip,
+// an IEEE division itself), the per-point work is one multiplication and two FMAs:
 //     q0 = RN(a*y);   r = a - b*q0 (exact, FMA);   q = RN(q0 + r*y)
 // -- Markstein's division step.  With a correctly rounded reciprocal, q is the correctly rounded quotient
 // whenever q0 is within one ulp of a/b (Markstein 1990; Muller et al., Handbook of Floating-Point
 // Arithmetic, section 4.7); q0 can be up to 1.5 ulp off, and then q still is RN(a/b + d) with |d| below
 // 1.7e-16 ulp, which differs from RN(a/b) only if a/b lies that close to a rounding boundary: about 3 in
 // 1e16 quotients, by one ulp (tests/div_hoisted_host.cpp: 228 million quotients, no difference).
-// Everything the three operations do not handle -- infinite or NaN operands, overflow, quotients in the
-// denormal range, a reciprocal that is not a normal number (inflx_recip then hands over NaN), a numerator
-// so small (< 2^-960) that the residual would underflow -- clears `ok`: the generated point stage then
-// evaluates the point again with IEEE divisions (staging.py, inflx_stage_point).  A zero numerator over a
-// regular denominator is regular too; a*y carries the sign a/b has.
+//
+// The three operations are only valid while nothing overflows or underflows on the way.  ONE comparison per
+// quotient establishes that (4.8 fma-equivalents per quotient in all, against 13.0):
+//   * inflx_recip hands over y = NaN unless 2^-500 <= |b| <= 2^500 (evaluated in the earlier stage);
+//   * the quotient is accepted iff |q| >= 2^-400.  Then |a| >= 2^-901, so the residual a - b*q0 is a multiple
+//     of 2^-1006 and exact; an infinite or NaN numerator, an overflowing product a*y and a NaN reciprocal all
+//     end as q = NaN, which fails the comparison; zero, tiny and denormal quotients fail it by magnitude.
+// A quotient that is not accepted clears `ok`: the tile kernel then evaluates that grid row again with IEEE
+// divisions (inflx_stage_point_ieee), so the stored values are those of the IEEE program always.  Rows inside
+// a NaN region of the model are evaluated twice for that reason -- correct, merely slower there.
 INFLX_FN double inflx_recip(double b) {
   const double y = 1.0 / b;
-  return __builtin_isnormal(y) ? y : __builtin_nan("");
+  const double m = __builtin_fabs(b);
+  return (m >= 0x1p-500 && m <= 0x1p500) ? y : __builtin_nan("");
+}
+
+// For a quotient whose numerator is a product of values of earlier stages the comparison is not needed at all:
+// the stages that produce the factors test them once against [2^-E, 2^E] (inflx_out_of_range, summed into one
+// flag per stage; E = 160 for at most three factors, 500 for the denominator), which bounds numerator and
+// quotient away from every overflow and underflow, and the point stage tests the sum of the flags once.
+template <int E>
+INFLX_FN double inflx_out_of_range(double x) {
+  const double m = __builtin_fabs(x);
+  return (m >= __builtin_ldexp(1.0, -E) && m <= __builtin_ldexp(1.0, E)) ? 0.0 : 1.0;  // NaN: out of range
+}
+
+INFLX_FN double inflx_div_by_hoisted_in_range(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  return __builtin_fma(r, y, q0);
 }
 
 INFLX_FN double inflx_div_by_hoisted(double a, double b, double y, bool& ok) {
   const double q0 = a * y;
   const double r = __builtin_fma(-b, q0, a);
   const double q = __builtin_fma(r, y, q0);
-  const bool normal = __builtin_isnormal(q);
-  ok = ok && ((normal && __builtin_fabs(a) >= 0x1p-960) || (a == 0.0 && q0 == 0.0));
-  return normal ? q : q0;
+#ifndef INFLX_DIVH_TRUST  // (experiments only: time the hot loop as if every quotient were accepted)
+  ok = ok && (__builtin_fabs(q) >= 0x1p-400);
+#endif
+  return q;
 }
 
 // reciprocal hyperbolic / trigonometric functions sympy may emit without a C99 spelling

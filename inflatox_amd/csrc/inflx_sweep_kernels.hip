@@ -310,12 +310,22 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 
 #if INFLX_HAS_QUICK_POINT
   // Hot loop: the point stage that divides by hoisted reciprocals.  A row in which some lane met an
-  // irregular quotient (NaN or infinite operands, overflow, a denormal result...) is only noted here and
+  // irregular quotient (NaN or infinite operands, overflow, a zero or denormal result...) is only noted here and
   // evaluated after the loop with IEEE divisions -- by the whole wavefront, since the row is stored as a
   // block -- so that the cold code costs the hot loop neither registers nor branches.
+  // Irregular quotients are usually structural: a numerator that is exactly zero in one grid column (sin 0, x1 = 0)
+  // fails in EVERY row of the wavefront that owns the column.  Such a wavefront would do all its rows twice
+  // and hold its workgroup's slot 2.2 times as long as its neighbours (measured: +10 % on the whole D5 sweep at
+  // 4096 columns); after two consecutive irregular rows it therefore stops trying and leaves the remaining rows
+  // to the IEEE loop directly.
   static_assert(kTileRows <= 64, "one bit per tile row");
   uint64_t redo = 0;
+  int streak = 0;  // consecutive irregular rows (wave-uniform)
   for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
+    if (streak >= 2) {
+      redo |= ~uint64_t(0) << r;  // rows r .. 63; rows >= nrows are masked below
+      break;
+    }
     const uint64_t row = row0 + r;
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
     InflxModelValues mv;
@@ -323,12 +333,15 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     inflx_stage_point_quick(x0, x1, A, U, Rs[r], C, mv, ok);
     if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // wave-uniform
       redo |= uint64_t(1) << r;
+      ++streak;
       continue;
     }
+    streak = 0;
     double o[K];
     apply_op<OP>(mv, o, a.accuracy);
     emit(o, row);
   }
+  if (nrows < 64) redo &= (uint64_t(1) << nrows) - 1;
   while (redo != 0) {
     const int r = __builtin_ctzll(redo);
     redo &= redo - 1;

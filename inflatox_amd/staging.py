@@ -19,10 +19,15 @@ this module never builds new sympy expressions from rewritten pieces.  It only
 
   * shares *structurally identical* sub-expressions (the same node is computed once: exact);
   * moves *whole* sub-expressions to the stage of the axes they depend on (exact);
-  * inside an n-ary product or sum, multiplies/adds the operands of one class first, in their
-    printed order (a re-association: rounding-level differences only, no cancellation of factors,
-    NaN/Inf propagate the same way);
-  * replaces ``pow(x, n)`` for small integer / half-integer n by a multiplication chain.
+  * moves the *leading* partial product ``((a*b)*c)`` of an n-ary product (the leading partial sum of
+    an n-ary sum, a whole denominator ``/(d1*d2*d3)``) to the lower stage when those leading operands
+    depend on fewer axes: C evaluates left to right, so that partial result is the very value the
+    reference computes on the way (exact; ``test_staging_does_not_change_a_single_bit``);
+  * replaces ``pow(x, n)`` for small integer / half-integer n by a multiplication chain (the one
+    deliberate rounding-level difference of the default mode).
+
+Re-association of products and sums by axis class (``group_quotient`` / ``group_terms``) exists only in
+the opt-in fast mode ``Compiler(regroup=True)``; it is not exact and never part of the parity path.
 
 Everything is done while printing: :class:`HIPInflatoxPrinter` asks the :class:`Stager` for the
 C expression of every child node, and the stager answers with either the child's own printed form
@@ -31,6 +36,7 @@ or the name of a stage variable that holds it.
 
 from __future__ import annotations
 
+import math
 import re
 import sys
 from collections import Counter, defaultdict
@@ -87,7 +93,12 @@ class HIPInflatoxPrinter(C99CodePrinter):
     reference-order registration pass (compiler.Compiler._number_parameters).
     """
 
-    MAX_INT_POW = 64
+    #: pow(x, n) becomes a multiplication chain for 2 <= |n| <= 16 (half-integer n/2 for |n| <= 33); the chain's
+    #: error grows like n/2 ulp against < 1 ulp for libm's pow, so larger exponents keep the pow() call.  The
+    #: example models use nothing beyond x^12.  A stand-alone negative power prints as 1.0/chain: where x^n
+    #: overflows this gives 0 while pow(x, -n) would still return a denormal -- accepted (inside products sympy
+    #: prints negative powers as denominators, exactly as the reference's C has them).
+    MAX_INT_POW = 16
 
     def __init__(self, names: dict, stager=None):
         super().__init__()
@@ -211,7 +222,8 @@ class HIPInflatoxPrinter(C99CodePrinter):
         if len(den) == 1:
             recip = self.stager.hoisted_reciprocal(den) if self.stager is not None else None
             if recip is not None:
-                return f"INFLX_DIVH({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
+                macro = "INFLX_DIVH_PURE" if self.stager.pure_numerator(num, num_s, den[0], den_s[0]) else "INFLX_DIVH"
+                return f"{macro}({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
             return sign + "*".join(num_s) + "/" + den_s[0]
         return sign + "*".join(num_s) + "/(" + "*".join(den_s) + ")"
 
@@ -302,6 +314,8 @@ class Stager:
         self.used_by = defaultdict(set)  # name -> stages (or "out") that read it
         self._mask = {}
         self._count = defaultdict(int)
+        self._by_text = {}  # (stage, right-hand side text) -> name of the variable that holds it
+        self.range_terms = {U: {}, R: {}, C: {}}  # operand text -> E: |operand| must lie in [2^-E, 2^E] (pure hoisted quotients)
         self._ctx = P
         self.refs = Counter()
         # identical nodes may be shared across the five functions only if no function-local
@@ -451,6 +465,57 @@ class Stager:
             return None
         return self._variable(_Group("recip", [d]), self.mask(d))
 
+    PURE_MAX_FACTORS = 4
+    PURE_BUDGET = 480  # |log2| allowed for the whole numerator; a numerator of k factors allows 480/k per factor
+
+    def pure_numerator(self, num, num_s, den, den_s):
+        """Is the numerator of this hoisted quotient a product of at most PURE_MAX_FACTORS values of earlier
+        stages (and modest numeric constants)?  Then whether Markstein's three operations are valid
+        (csrc/inflx_device_math.h) does not depend on the grid point but on the row, the column and the
+        parameters separately: with each of k factors in [2^-E, 2^E], E = 480/k, and the denominator in
+        [2^-500, 2^500], the numerator lies in [2^-490, 2^490] and nothing can overflow, underflow or lose the
+        exactness of the residual.  The factors are recorded per stage; each stage exports ONE flag (0.0 = all
+        its operands in range), the point stage tests the three flags once instead of comparing every quotient."""
+        if not self.hoist_reciprocals or self._ctx != P:
+            return False
+        factors = []
+        budget = 0.0
+        for item, text in zip(num, num_s):
+            if not item.free_symbols:
+                try:
+                    v = abs(float(item))
+                except (TypeError, ValueError):
+                    return False
+                if v == 0.0:
+                    return False
+                budget += abs(math.log2(v))
+                continue
+            m = self.mask(item)
+            if m == P:
+                return False
+            factors.append((m, text.lstrip("-")))
+        if not factors or len(factors) > self.PURE_MAX_FACTORS or budget > 10.0:
+            return False
+        e = self.PURE_BUDGET // len(factors)
+        for m, text in factors:
+            self.range_terms[m][text] = min(e, self.range_terms[m].get(text, e))
+        self.range_terms[self.mask(den)][den_s] = min(500, self.range_terms[self.mask(den)].get(den_s, 500))
+        return True
+
+    def finish_range_flags(self):
+        """One exported flag per stage that has range terms; returns the names the point stage must test."""
+        names = []
+        for m in (U, R, C):
+            if self.range_terms[m]:
+                name = f"{STAGE_PREFIX[m]}_flag"
+                self.stage_of[name] = m
+                terms = [f"inflx_out_of_range<{e}>({text})" for text, e in self.range_terms[m].items()]
+                self.lines[m].append(f"  const double {name} = " + " + ".join(terms) + ";")
+                self.used_by[name].add(P)
+                names.append(name)
+        self.exports = {m: [n for n, st in self.stage_of.items() if st == m and (self.used_by[n] - {m})] for m in (U, R, C)}
+        return names
+
     def group_quotient(self, num, den):
         """Fast mode only (``regroup``): inside a product printed in stage ctx, the numerator and
         denominator factors of each lower class become ONE stage variable num/den, so that the division
@@ -531,12 +596,22 @@ class Stager:
             else:
                 text = self.printer.print_node(e)
             self._ctx = saved
-            k = self._count[m]
-            self._count[m] += 1
-            name = f"{STAGE_PREFIX[m]}_{k}"
+            # Value numbering on the emitted text: a statement whose right-hand side is, character for
+            # character, one that was emitted before (operands are literals, args[k], x0/x1 and stage
+            # variables, so equal text means equal value) is that earlier variable.  This is what shares work
+            # between the five functions when the reference ran sympy.cse per function (cse=True): there every
+            # function has cse symbols of its own, nodes cannot be compared across functions, and without
+            # this each function re-evaluated the sub-expressions it has in common with the others.  Exact:
+            # statements are merged whole, no statement is rewritten.
+            name = self._by_text.get((m, text))
+            if name is None:
+                k = self._count[m]
+                self._count[m] += 1
+                name = f"{STAGE_PREFIX[m]}_{k}"
+                self.stage_of[name] = m
+                self.lines[m].append(f"  const double {name} = {text};")
+                self._by_text[(m, text)] = name
             self.named[e] = name
-            self.stage_of[name] = m
-            self.lines[m].append(f"  const double {name} = {text};")
         return self._reference(name) if reference else name
 
     def _sum_text(self, terms):
@@ -595,6 +670,7 @@ def emit_stage_header(
             functions.append(([], [e]))
     functions.append(cse_vector(basis_v) if cse_vector is not None else ([], basis_v))
     st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals)
+    range_flags = st.finish_range_flags()
 
     idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}
 
@@ -679,8 +755,10 @@ def emit_stage_header(
     lines = list(st.lines[P])
     for field, text in zip(OUTPUT_FIELDS, st.outputs):
         lines.append(f"  mv.{field} = {text};")
+    if range_flags:
+        lines.append("  INFLX_RANGE_CHECK(" + " + ".join(range_flags) + ");")
     point_body = "\n".join(place_imports(imports_for(P, "out"), lines))
-    n_hoisted = point_body.count("INFLX_DIVH(")
+    n_hoisted = point_body.count("INFLX_DIVH(") + point_body.count("INFLX_DIVH_PURE(")
     out.append("// everything that depends on both axes, and the five model values")
     if n_hoisted:
         # The same statements twice.  `quick` forms the quotients whose denominator comes from an earlier
@@ -690,16 +768,21 @@ def emit_stage_header(
         # is evaluated again by `ieee`, so the values are those of `ieee` always.
         out.append(f"// {n_hoisted} quotients per point by a denominator of an earlier stage")
         out.append("#define INFLX_HAS_QUICK_POINT 1")
+        out.append(f"// ({point_body.count('INFLX_DIVH_PURE(')} of them with a numerator made of earlier-stage values only: validity decided per row / column / sweep)")
         out.append("#define INFLX_DIVH(a, b, y) inflx_div_by_hoisted((a), (b), (y), ok)")
+        out.append("#define INFLX_DIVH_PURE(a, b, y) inflx_div_by_hoisted_in_range((a), (b), (y))")
+        out.append("#define INFLX_RANGE_CHECK(flags) ok = ok && ((flags) == 0.0)")
         out.append(f"INFLX_FN void inflx_stage_point_quick({point_args}, bool& ok) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n")
         out.append("#define INFLX_DIVH(a, b, y) ((a) / (b))")
+        out.append("#define INFLX_DIVH_PURE(a, b, y) ((a) / (b))")
+        out.append("#define INFLX_RANGE_CHECK(flags) (void)(flags)")
         out.append(f"INFLX_FN void inflx_stage_point_ieee({point_args}) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n")
         out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
         out.append("  bool ok = true;")
         out.append("  inflx_stage_point_quick(x0, x1, args, U, R, C, mv, ok);")
@@ -711,7 +794,11 @@ def emit_stage_header(
         out.append(point_body)
         out.append("}\n")
     out.append(_emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector))
-    info = dict(nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()})
+    sweep_lines = "\n".join(ln for ln in point_body.splitlines() if not ln.lstrip().startswith(("mv.b0", "mv.b1")))
+    info = dict(
+        nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()},
+        hoisted_quotients=sweep_lines.count("INFLX_DIVH(") + sweep_lines.count("INFLX_DIVH_PURE("),
+    )  # fmt: skip
     return "\n".join(out), info
 
 

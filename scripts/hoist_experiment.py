@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""Experiment (GPU box): tile-kernel time of the opt-in hoisted-reciprocal division against the default,
-at 2 and 1 wavefronts per SIMD (256 / 512 registers per lane)."""
+"""Experiment (GPU box): tile-kernel time of the hoisted-reciprocal division against the default.
+usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, trust (-DINFLX_DIVH_TRUST: accept every quotient), w1 (1 wave/SIMD)"""
 import os
 import sys
 
@@ -15,13 +15,24 @@ from inflatox_amd.compiler import Compiler  # noqa: E402
 n = 4096
 stream = torch.cuda.current_stream().cuda_stream
 out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
-for name in sys.argv[1:] or ["d5", "egno"]:
+for case in sys.argv[1:] or ["d5", "d5:hoist", "egno", "egno:hoist"]:
+    name, _, fl = case.partition(":")
+    fl = set(fl.split(",")) - {""}
     spec = example_models.get(name)
-    for hoist in (False, True):
-        for waves in (2, 1):
-            kw = dict(spec.compiler_kwargs)
-            flags = Compiler.default_hipcc_flags + [f"-DINFLX_MIN_WAVES={waves}"]
-            art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, hoist_reciprocals=hoist, **kw).compile()
-            lib = _native.InflatoxDevLib(art.shared_object_path)
-            ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=stream, repeats=30) for _ in range(3))
-            print(f"{name:6s} hoist={hoist!s:5s} waves/SIMD={waves}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
+    kw = dict(spec.compiler_kwargs)
+    flags = list(Compiler.default_hipcc_flags)
+    if "w1" in fl:
+        flags.append("-DINFLX_MIN_WAVES=1")
+    if "trust" in fl:
+        flags.append("-DINFLX_DIVH_TRUST=1")
+    for f in fl:
+        if f.startswith("D"):
+            flags.append("-" + f)
+    ext = spec.extent
+    if "inner" in fl:  # keep away from the first row and the first column
+        x0a, x0b, x1a, x1b = ext
+        ext = (x0a + 0.1 * (x0b - x0a), x0b, x1a + 0.1 * (x1b - x1a), x1b)
+    art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, hoist_reciprocals="hoist" in fl, **kw).compile()
+    lib = _native.InflatoxDevLib(art.shared_object_path)
+    ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, out.data_ptr(), out.numel() * 8, ext, n, n, stream=stream, repeats=30) for _ in range(3))
+    print(f"{case:28s}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)

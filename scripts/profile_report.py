@@ -32,7 +32,7 @@ def counter(d, name):
     return {k: {"launches": len(v), "mean_KB": sum(v.values()) / len(v), "min_KB": min(v.values()), "max_KB": max(v.values())} for k, v in per.items()}
 
 
-def main(d, rnd="01"):
+def main(d, rnd="02"):
     out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(d))), "profiles")
     stats = kernel_stats(os.path.join(d, "stats"))
     with open(os.path.join(out, f"r{rnd}_bench_hyperbolic8192_kernel_stats.csv"), "w") as fh:
@@ -63,6 +63,16 @@ def main(d, rnd="01"):
             rec["algorithmic_bytes"] = 48 * 8192 * 8192
             rec["ratio"] = (wb + rb) / rec["algorithmic_bytes"]
         traffic[k] = rec
+    # stamp: the code object these launches came from (bench.py quotes `traffic` only while it loads the same one)
+    stamp = None
+    for name in ("bench_under_rocprof.json", "bench.json"):
+        try:
+            lines = [ln for ln in open(os.path.join(d, name)).read().splitlines() if ln.startswith("{")]
+            stamp = json.loads(lines[-1])["roofline"]["code_object"]
+            break
+        except (OSError, IndexError, KeyError, ValueError):
+            continue
+    traffic["code_objects"] = {k: stamp for k in traffic["bytes_per_launch"]}
     json.dump(traffic, open(os.path.join(out, f"r{rnd}_traffic.json"), "w"), indent=1)
     for name, target in (("bench.json", f"r{rnd}_bench.json"), ("bench_under_rocprof.json", f"r{rnd}_bench_under_rocprof.json")):
         src = os.path.join(d, name)

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Turn the rocprofv3 --pmc databases of scripts/valu_probe.py into a per-model table:
 VALU wavefront-instructions per grid point, share of wave cycles issuing VALU, kernel duration.
-usage: valu_report.py OUT.json DB [DB ...]   (one DB per counter group; dispatch order identifies the model)"""
+usage: valu_report.py OUT.json CODE_OBJECTS.json DB [DB ...]   (one DB per counter group; dispatch order identifies the model;
+CODE_OBJECTS.json = the stamps scripts/valu_probe.py wrote: bench.py quotes a record only for the code object it was measured on)"""
 import collections
 import json
 import sqlite3
@@ -25,7 +26,7 @@ def dispatches(db):
     return list(per.values())
 
 
-def main(out_path, dbs):
+def main(out_path, stamp_path, dbs):
     merged = None
     for db in dbs:
         rows = [r for r in dispatches(db) if r["kernel"].startswith("inflx_sweep_") and "rowvals" not in r["kernel"]]
@@ -38,7 +39,7 @@ def main(out_path, dbs):
                 a.update({k: v for k, v in b.items() if k not in ("kernel", "us")})
     # two sweeps per model, in CASES order; keep the second (warm) one
     assert len(merged) == 2 * len(CASES), len(merged)
-    table = {}
+    table = {"code_objects": json.load(open(stamp_path)), "_units": "WRITE_SIZE / FETCH_SIZE in KB per launch; FETCH_SIZE must be doubled on gfx950 (MI355X_MICROARCH.md); SQ_* cycle counters in quad-cycles"}
     for k, (name, n) in enumerate(CASES):
         r = merged[2 * k + 1]
         pts = n * n
@@ -49,14 +50,21 @@ def main(out_path, dbs):
             rec["valu_issue_ceiling_points_per_s"] = FP64_LANE_RATE / rec["valu_insts_per_point"]
         if "SQ_ACTIVE_INST_VALU" in r and "SQ_WAVE_CYCLES" in r:
             rec["valu_active_share_of_wave_cycles"] = r["SQ_ACTIVE_INST_VALU"] / r["SQ_WAVE_CYCLES"]
-        for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY"):
+        if "WRITE_SIZE" in r and "FETCH_SIZE" in r:
+            rec["hbm_bytes_per_launch"] = {"write": r["WRITE_SIZE"] * 1024, "fetch_x2": r["FETCH_SIZE"] * 2048, "algorithmic": 48 * pts}
+            rec["traffic_ratio"] = (r["WRITE_SIZE"] * 1024 + r["FETCH_SIZE"] * 2048) / (48 * pts)
+        if "SQ_LDS_BANK_CONFLICT" in r and "SQ_LDS_IDX_ACTIVE" in r:
+            rec["lds_bank_conflict_share_of_lds_cycles"] = r["SQ_LDS_BANK_CONFLICT"] / max(r["SQ_LDS_IDX_ACTIVE"], 1)
+        for c in ("SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_WR", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_ANY", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "WRITE_SIZE", "FETCH_SIZE"):
             if c in r:
                 rec[c] = r[c]
         table[name] = rec
     json.dump(table, open(out_path, "w"), indent=1)
     for name, rec in table.items():
-        print(name, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rec.items() if k in ("kernel", "valu_insts_per_point", "valu_active_share_of_wave_cycles", "kernel_us_under_counters")})
+        if not isinstance(rec, dict) or "kernel" not in rec:
+            continue
+        print(name, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in rec.items() if k in ("kernel", "valu_insts_per_point", "valu_active_share_of_wave_cycles", "kernel_us_under_counters", "traffic_ratio", "lds_bank_conflict_share_of_lds_cycles")})
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2:])
+    main(sys.argv[1], sys.argv[2], sys.argv[3:])

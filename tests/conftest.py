@@ -71,3 +71,20 @@ def generalised_al(art):
     al = GeneralisedAL.__new__(GeneralisedAL)
     InflationCondition.__init__(al, art, validate_basis=False)
     return al
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Parity statistics of the run (per tolerance.check call: excluded fraction, worst ratio to the allowance):
+    the numbers the per-model KAPPA and the exclusion caps of tests/tolerance.py are set from."""
+    try:
+        import json
+
+        import tolerance
+
+        if tolerance.STATS:
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "parity_stats.json"), "w") as fh:
+                json.dump(tolerance.STATS, fh, indent=0)
+    except Exception:  # noqa: BLE001 -- statistics only
+        pass

@@ -247,8 +247,13 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
     """The per-point divisions by row/column/sweep-only denominators go through inflx_div_by_hoisted, and the
     program with them is bit-identical to the one with plain divisions on the golden grid and random points."""
     _, with_h = header_for(name, hoist_reciprocals=True)
-    _, without = header_for(name)
+    _, without = header_for(name, hoist_reciprocals=False)
     assert "INFLX_DIVH(" in with_h and "inflx_stage_point_quick" in with_h and "INFLX_DIVH" not in without
+    # the automatic choice (hoist_reciprocals=None, the default): on where enough divisions leave the point stage
+    _, auto = header_for(name)
+    assert auto == (with_h if name in ("d5", "egno") else without)
+    if name == "d5":
+        assert "INFLX_DIVH_PURE(" in with_h and "r_flag" in with_h and "INFLX_RANGE_CHECK(u_flag + r_flag + c_flag)" in with_h
     a, b = HostTwin(with_h), HostTwin(without)
     g = golden(name)
     n0, n1 = (int(v) for v in g["g64_shape"])

@@ -1,8 +1,10 @@
 """How close must the GPU sweep be to the reference?  -- the acceptance criterion of the parity tests.
 
 Bar (BASELINE.json north_star): <= 1e-10 relative on the six output arrays, NaN pattern and +-Inf
-exact.  For well-conditioned models (README hyperbolic model, the reference's doc model) that is
-asserted literally.  Three of the reference's test models, however, are *evaluated* by the reference
+exact.  For the README hyperbolic model (the model north_star states the bar for) that is asserted literally
+on every grid, and for the reference's doc model on its golden grids (measured: 1.6e-13; on a 1000 x 1000 grid
+isolated points next to zero crossings of v10 reach 5e-10, so there the criterion below applies -- see STRICT /
+STRICT_GOLDEN in tests/test_parity_gpu.py).  Three of the reference's test models, however, are *evaluated* by the reference
 in an ill-conditioned way: the generated C subtracts nearly equal terms, so its float64 result
 differs from the exact value of its own expression by far more than 1e-10 (EGNO: median 5e-9,
 worst 1e-6 relative; angular: 1e-3 next to the zero crossing of v10; D5: arbitrary at theta = k*pi).
@@ -33,7 +35,18 @@ import itertools
 import numpy as np
 
 RTOL = 1e-10
-KAPPA = 64.0  # multiple of the reference's measured rounding error granted to the GPU
+# Multiple of the reference's measured rounding error granted to the GPU, per model: about four times the
+# largest |gpu - ref| / E observed on MI355X (profiles/r0N_parity_report.txt; tests/tools/gpu_parity_report.py
+# prints the ratios), so that a regression of the kernels' arithmetic by a factor of a few fails.  D5 keeps 64:
+# next to its singular lines v10 has been observed at half of that.
+KAPPA_BY_MODEL = {"hyperbolic": 4.0, "doc": 16.0, "angular": 24.0, "egno": 16.0, "d5": 64.0}
+KAPPA = 64.0  # models not listed
+# Largest fraction of compared values that may be left out of the value comparison -- because the reference's
+# own error is unbounded there (allowance infinite: singular lines of D5, the r = 0 row of the doc model) or
+# because its NaN-ness is not robust under few-ulp moves -- before a test fails instead of passing vacuously.
+# About four times the largest fraction observed over the GPU suite (gpurun_out/parity_stats.json).
+EXCLUDED_CAP_BY_MODEL = {"hyperbolic": 0.05, "doc": 0.02, "angular": 0.02, "egno": 0.005, "d5": 0.08}
+EXCLUDED_CAP = 0.05
 ULPS = 8.0  # libm-level disagreement granted on the model values themselves, in float64 ulps
 EPS = np.finfo(np.float64).eps
 
@@ -111,15 +124,19 @@ def reference_error(name, p, pts, copies: int = 12, seed: int = 1234):
     return env, flaky
 
 
-def allowance_raw(ref_raw: np.ndarray, env: np.ndarray) -> np.ndarray:
+def kappa_for(model: str | None) -> float:
+    return KAPPA_BY_MODEL.get(model, KAPPA)
+
+
+def allowance_raw(ref_raw: np.ndarray, env: np.ndarray, model: str | None = None) -> np.ndarray:
     with np.errstate(all="ignore"):
-        return RTOL * np.abs(ref_raw) + KAPPA * env
+        return RTOL * np.abs(ref_raw) + kappa_for(model) * env
 
 
-def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn) -> np.ndarray:
+def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn, model: str | None = None) -> np.ndarray:
     """Largest change of fn(raw) when every model value moves by +-(ULPS ulps + KAPPA*E)."""
     with np.errstate(all="ignore"):
-        delta = ULPS * EPS * np.abs(ref_raw) + KAPPA * np.where(np.isfinite(env), env, 0.0)
+        delta = ULPS * EPS * np.abs(ref_raw) + kappa_for(model) * np.where(np.isfinite(env), env, 0.0)
         base = fn(ref_raw)
         worst = np.zeros_like(base)
         for signs in itertools.product((-1.0, 1.0), repeat=5):
@@ -132,13 +149,24 @@ def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn) -> np.ndarray:
         return RTOL * np.abs(base) + 2.0 * worst
 
 
-def check(got, ref, allowed, flaky=None, what=""):
+STATS = []  # one record per check() call: what, compared values, excluded fraction, worst ratio (conftest dumps it)
+
+
+def check(got, ref, allowed, flaky=None, what="", model: str | None = None):
     """NaN pattern exact, +-Inf exact (with sign), finite values within `allowed`.  `flaky` marks the
     points where the reference's own NaN-ness is not robust (see reference_error); the NaN/Inf pattern
-    is not compared there.  Returns the largest |got-ref| / allowed over the compared points (<= 1 passes)."""
+    is not compared there.  The fraction of values left out of the value comparison (infinite allowance, or
+    flaky) is bounded by EXCLUDED_CAP_BY_MODEL.  Returns the largest |got-ref| / allowed over the compared
+    points (<= 1 passes)."""
     got, ref, allowed = np.asarray(got), np.asarray(ref), np.asarray(allowed)
     assert got.shape == ref.shape, (what, got.shape, ref.shape)
     firm = np.ones(ref.shape, dtype=bool) if flaky is None else ~np.broadcast_to(flaky, ref.shape)
+    loose = np.isfinite(ref) & ~np.isfinite(np.broadcast_to(allowed, ref.shape))
+    excluded = float((loose | ~firm).sum()) / max(1, ref.size)
+    cap = EXCLUDED_CAP_BY_MODEL.get(model, EXCLUDED_CAP)
+    record = {"what": what, "model": model, "values": int(ref.size), "excluded": excluded, "worst_ratio": None}
+    STATS.append(record)
+    assert excluded <= cap, f"{what}: {100 * excluded:.2f} % of the values are outside the value comparison (cap {100 * cap:.2f} %)"
     assert np.array_equal(np.isnan(got)[firm], np.isnan(ref)[firm]), f"{what}: NaN pattern differs"
     inf_r = np.isinf(ref) & firm
     assert np.array_equal(np.isinf(got) & firm, inf_r), f"{what}: Inf pattern differs"
@@ -151,6 +179,7 @@ def check(got, ref, allowed, flaky=None, what=""):
     with np.errstate(all="ignore"):
         ratio = np.abs(got[fin] - ref[fin]) / np.maximum(allowed[fin], np.finfo(float).tiny)
     worst = float(ratio.max())
+    record["worst_ratio"] = worst
     assert worst <= 1.0, f"{what}: |gpu-ref| exceeds the allowance by x{worst:.3g} ({int((ratio > 1).sum())} of {ratio.size} points)"
     return worst
 

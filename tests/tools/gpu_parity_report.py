@@ -27,11 +27,11 @@ for name in sys.argv[1:] or ["hyperbolic", "doc", "angular", "egno", "d5"]:
         got_raw = lib.sweep_host(_native.OP_RAW, spec.args, ext, n0, n1)
         got_out = lib.sweep_host(_native.OP_COMPLETE, spec.args, ext, n0, n1)
         for key, got, ref, allowed, fl in (
-            ("raw", got_raw, ref_raw, tol.allowance_raw(ref_raw, env), flaky),
-            ("out", got_out, ref_out, tol.allowance_derived(ref_raw, env, tol.epilogue), flaky.any(axis=-1, keepdims=True)),
+            ("raw", got_raw, ref_raw, tol.allowance_raw(ref_raw, env, name), flaky),
+            ("out", got_out, ref_out, tol.allowance_derived(ref_raw, env, tol.epilogue, name), flaky.any(axis=-1, keepdims=True)),
         ):
             try:
-                tol.check(got, ref, allowed, fl, f"{name}/{key}")
+                tol.check(got, ref, allowed, fl, f"{name}/{key}", model=name)
                 verdict = "PASS"
             except AssertionError as exc:
                 verdict = f"FAIL {exc}"
