@@ -239,13 +239,15 @@ class Compiler:
       from the reference where a model cancels catastrophically);
     * ``exact_constants`` (default False): full-precision pi, e, ... instead of the reference's
       12-digit fallback constants;
-    * ``hoist_reciprocals`` (default False): a per-point quotient whose denominator is known one stage
-      earlier is formed from the correctly rounded reciprocal of that denominator with Markstein's
-      multiply-FMA-FMA step instead of a 13-instruction IEEE division (csrc/inflx_device_math.h: the same
-      correctly rounded quotient; irregular points are re-evaluated with IEEE divisions).  Opt-in because
-      it does not pay enough: the default program's independent divisions already overlap well, and the
-      quick stage's register pressure costs what the shorter divisions gain (D5 5 % faster, EGNO 10 %
-      slower on MI355X).
+    * ``hoist_reciprocals`` (default None = automatic): a per-point quotient whose denominator is known one
+      stage earlier is formed from the correctly rounded reciprocal of that denominator with Markstein's
+      multiply-FMA-FMA step instead of an 11-instruction IEEE division (csrc/inflx_device_math.h: the same
+      correctly rounded quotient; rows with irregular operands are re-evaluated with IEEE divisions, so the
+      stored values are the IEEE program's bit for bit).  4.8 fma-equivalents of issue time per quotient
+      against 13.0, and nothing but the three operations when the numerator is a product of earlier-stage
+      values (validity then follows from per-row / per-column / per-sweep range flags).  ``None`` turns it on
+      when at least ``HOIST_MIN_QUOTIENTS`` divisions of the five sweep values qualify (D5: 29 of 53 divisions,
+      0.592 -> 0.519 ms per 4096^2 sweep on MI355X); ``True`` / ``False`` force it.
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order, spherical
@@ -255,7 +257,7 @@ class Compiler:
 
     #: `hoist_reciprocals=None` turns the hoisted-reciprocal division on when the five sweep values contain at least
     #: this many per-point quotients by a denominator of an earlier stage
-    HOIST_MIN_QUOTIENTS = 6
+    HOIST_MIN_QUOTIENTS = 16  # measured at 4096^2: D5 (29) 0.592 -> 0.519 ms; EGNO (12) 0.457 -> 0.465 ms; doc (1) 0.263 -> 0.269 ms
     c_prefix = "inflx_auto_"
     lib_prefix = "libinflx_auto_"
 
@@ -407,7 +409,7 @@ class Compiler:
 
         if self.hoist_reciprocals is None:
             # automatic: the second copy of the point stage and the bookkeeping around it only pay when enough
-            # IEEE divisions leave the per-point stage (D5: 29 of 53; the documentation model: 1 of 16)
+            # IEEE divisions leave the per-point stage (D5: 29 of 53; EGNO: 12 of 30; the documentation model: 1 of 16)
             text, info = emit(self.staged)
             if info["hoisted_quotients"] < self.HOIST_MIN_QUOTIENTS:
                 text, info = emit(False)

@@ -673,6 +673,7 @@ def test_geometry_fuzz_sweeps_equal_point_evaluation(name, gpu_lib):
         assert np.array_equal(got.reshape(want.shape), want, equal_nan=True), what
         # the device-resident variant of the same sweep
         out = torch.full((want.size,), -7.0, dtype=torch.float64, device="cuda:0")
+        torch.cuda.synchronize()  # the fill ran on torch's default stream; stream handle 0 below means the model's own (non-blocking) stream
         lib.sweep_device(op, args, out.data_ptr(), out.numel() * 8, ss, n0, n1, row_begin=rb, row_count=rc, layout=layout, stream=torch.cuda.current_stream().cuda_stream)
         torch.cuda.synchronize()
         assert np.array_equal(out.cpu().numpy().reshape(want.shape), want, equal_nan=True), what
@@ -733,8 +734,8 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
     _, art_h = workloads.artifact_for(name, hoist_reciprocals=True)
     lib_h = gpu_lib.InflatoxDevLib(art_h.shared_object_path)
     assert art_h.stage_info["hoisted_quotients"] >= 6 and art0.stage_info["hoisted_quotients"] == 0
-    # the default (automatic) choice for these two models is the hoisted program
-    assert devlib(name, gpu_lib)[1].stage_info["hoisted_quotients"] == art_h.stage_info["hoisted_quotients"]
+    # the default (automatic) choice: the hoisted program for D5 (29 quotients), the plain one for EGNO (12: does not pay)
+    assert devlib(name, gpu_lib)[1].stage_info["hoisted_quotients"] == (art_h.stage_info["hoisted_quotients"] if name == "d5" else 0)
     ss = np.array(spec.extent).reshape(2, 2)
     wide = np.array([[spec.extent[0] - 0.3 * (spec.extent[1] - spec.extent[0]), spec.extent[1]], [spec.extent[2], spec.extent[3]]])
     # the third grid starts exactly at x1 = 0 and x0 = 0 where the models have them in range: structural zeros (a

@@ -251,7 +251,7 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
     assert "INFLX_DIVH(" in with_h and "inflx_stage_point_quick" in with_h and "INFLX_DIVH" not in without
     # the automatic choice (hoist_reciprocals=None, the default): on where enough divisions leave the point stage
     _, auto = header_for(name)
-    assert auto == (with_h if name in ("d5", "egno") else without)
+    assert auto == (with_h if name == "d5" else without)
     if name == "d5":
         assert "INFLX_DIVH_PURE(" in with_h and "r_flag" in with_h and "INFLX_RANGE_CHECK(u_flag + r_flag + c_flag)" in with_h
     a, b = HostTwin(with_h), HostTwin(without)

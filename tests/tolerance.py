@@ -38,14 +38,18 @@ RTOL = 1e-10
 # Multiple of the reference's measured rounding error granted to the GPU, per model: about four times the
 # largest |gpu - ref| / E observed on MI355X (profiles/r0N_parity_report.txt; tests/tools/gpu_parity_report.py
 # prints the ratios), so that a regression of the kernels' arithmetic by a factor of a few fails.  D5 keeps 64:
-# next to its singular lines v10 has been observed at half of that.
+# next to its singular lines v10 has been observed at half of that.  Round 2, whole GPU suite, largest
+# |gpu - ref| / allowance per model with these values: doc 0.20, angular 0.13, EGNO 0.23, D5 0.26, hyperbolic 0.00.
 KAPPA_BY_MODEL = {"hyperbolic": 4.0, "doc": 16.0, "angular": 24.0, "egno": 16.0, "d5": 64.0}
 KAPPA = 64.0  # models not listed
 # Largest fraction of compared values that may be left out of the value comparison -- because the reference's
 # own error is unbounded there (allowance infinite: singular lines of D5, the r = 0 row of the doc model) or
 # because its NaN-ness is not robust under few-ulp moves -- before a test fails instead of passing vacuously.
-# About four times the largest fraction observed over the GPU suite (gpurun_out/parity_stats.json).
-EXCLUDED_CAP_BY_MODEL = {"hyperbolic": 0.05, "doc": 0.02, "angular": 0.02, "egno": 0.005, "d5": 0.08}
+# Two to four times the largest fraction observed over the GPU suite (tests/conftest.py writes every call's
+# numbers to gpurun_out/parity_stats.json; round 2: hyperbolic 3.1 % -- the v11 = -inf row of the 16 x 16 golden
+# grid --, doc 0, angular 0.02 %, EGNO 0, D5 4.95 % on the 16 x 16 golden grid, whose columns hit the singular
+# lines theta = k*pi/2 exactly, 1.2 % on 64 x 48).
+EXCLUDED_CAP_BY_MODEL = {"hyperbolic": 0.08, "doc": 0.01, "angular": 0.005, "egno": 0.002, "d5": 0.10}
 EXCLUDED_CAP = 0.05
 ULPS = 8.0  # libm-level disagreement granted on the model values themselves, in float64 ulps
 EPS = np.finfo(np.float64).eps
