@@ -143,7 +143,9 @@ def secondary_workloads(_native, workloads, torch, np, device, stream):
             if name == "d5" and P > 1:
                 rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)  # a1
             buf = torch.empty((P, n, n, 6), dtype=torch.float64, device=f"cuda:{device}")
-            ms = lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats)
+            # best of three batches of back-to-back launches: a single short batch sits inside the clock governor's
+            # transient and reads 10-15 % slow
+            ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
             pps = P * n * n / (ms * 1e-3)
             cid = code_object_id(art.shared_object_path)
             valu, src = recorded("valu", name, cid)
@@ -151,7 +153,7 @@ def secondary_workloads(_native, workloads, torch, np, device, stream):
                 "workload": text,
                 "kernel": "inflx_sweep_tile_complete",
                 "ms": ms,
-                "repeats": repeats,
+                "timing": f"HIP events around {repeats} back-to-back launches, best of 3 such batches",
                 "points_per_s": pps,
                 "hbm_frac": BYTES_PER_POINT * pps / 1e9 / HBM_PEAK_GBPS,
                 "code_object": cid,
