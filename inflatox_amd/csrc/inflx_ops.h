@@ -128,9 +128,14 @@ INFLX_FN void inflx_op_complete_analysis(const InflxModelValues& m, double out[6
   const double epsilon_v = m.g / inflx_sq(v);
   const double vtt = (v00 * inflx_sq(v10) + v11 * inflx_sq(v00) - 2. * v00 * inflx_sq(v10)) / (inflx_sq(v00) + inflx_sq(v10));
   const double vt2 = epsilon_v * (1. / (1. + inflx_sq(v00 / v10)));
-  const double epsilon_h = 3. * (epsilon_v - vt2) * (1. / (epsilon_v + fabs(vtt) / v - vt2));
+  // The reference divides twice by v here: |vtt| / v (below) and vtt / v (omega).  Rounding to nearest is symmetric in
+  // the sign, so |vtt| / v is exactly |vtt / v| with the sign of v (zeros, infinities and NaN included): one IEEE
+  // division instead of two, not a bit changed.
+  const double vtt_over_v = vtt / v;
+  const double abs_vtt_over_v = __builtin_copysign(fabs(vtt_over_v), v);
+  const double epsilon_h = 3. * (epsilon_v - vt2) * (1. / (epsilon_v + abs_vtt_over_v - vt2));
   const double delta = inflx_atan_nonneg(fabs(v10 / v00));
-  const double omega = sqrt((vtt / v) * (3. - epsilon_h));
+  const double omega = sqrt(vtt_over_v * (3. - epsilon_h));
   const double eta_parallel = omega * inflx_tan_quadrant1(delta) - 3.;
   out[0] = consistency;
   out[1] = epsilon_v;

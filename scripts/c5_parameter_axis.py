@@ -37,11 +37,11 @@ def main():
     if rehearse:
         local %= max(1, torch.cuda.device_count())
     comm = "cpu" if rehearse else f"cuda:{local}"
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # before the first HIP call of the process
     torch.cuda.set_device(local)
     if world > 1:
         import torch.distributed as dist
 
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if rehearse:
             dist.init_process_group("gloo")
         else:
@@ -56,7 +56,9 @@ def main():
     mine = rows[plan.p_begin : plan.p_begin + plan.p_count]
     out = torch.empty((plan.p_count, plan.row_count, n, 6), dtype=torch.float64, device=f"cuda:{local}")
     stream = torch.cuda.Stream(device=f"cuda:{local}")
-    lib.sweep_device(_native.OP_COMPLETE, mine[:1], out.data_ptr(), out[:1].numel() * 8, spec.extent, n, n, stream=stream.cuda_stream)  # warm-up
+    # warm-up: one parameter row of this rank's own block (the same row range as the timed call: a rank of a
+    # row-sharded plan owns fewer than n rows, and the buffer is sized for its share)
+    lib.sweep_device(_native.OP_COMPLETE, mine[:1], out.data_ptr(), out[:1].numel() * 8, spec.extent, n, n, row_begin=plan.row_begin, row_count=plan.row_count, stream=stream.cuda_stream)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

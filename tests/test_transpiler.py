@@ -261,3 +261,20 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
         assert np.array_equal(a.grid(op, g["args"], g["g64_extent"], n0, n1), b.grid(op, g["args"], g["g64_extent"], n0, n1), equal_nan=True)
     ext = example_models.get(name).extent
     assert np.array_equal(a.grid(0, g["args"], ext, 150, 130), b.grid(0, g["args"], ext, 150, 130), equal_nan=True)
+
+
+def test_abs_quotient_sign_identity_used_by_the_epilogue():
+    """csrc/inflx_ops.h forms |vtt| / v (anguelova.rs:125) as copysign(|vtt / v|, v) to save one IEEE division:
+    exact, because rounding to nearest is symmetric in the sign -- random operands over the whole exponent range,
+    every pair of special values, bit for bit (NaN = NaN)."""
+    rng = np.random.default_rng(3)
+    bits = rng.integers(0, 2**64, size=2_000_000, dtype=np.uint64)
+    a, b = bits[:1_000_000].view(np.float64), bits[1_000_000:].view(np.float64)
+    sp = np.array([0.0, -0.0, 1.0, -1.0, np.inf, -np.inf, np.nan, 5e-324, -5e-324, 2.2250738585072014e-308, 1.7976931348623157e308, -1.7976931348623157e308, 3.0, 1 / 3])
+    a = np.concatenate([a, np.repeat(sp, len(sp))])
+    b = np.concatenate([b, np.tile(sp, len(sp))])
+    with np.errstate(all="ignore"):
+        want = np.abs(a) / b
+        got = np.copysign(np.abs(a / b), b)
+    same = (want.view(np.uint64) == got.view(np.uint64)) | (np.isnan(want) & np.isnan(got))
+    assert same.all(), (a[~same][:5], b[~same][:5])
