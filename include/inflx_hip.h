@@ -148,7 +148,8 @@ int inflx_sweep_device(inflx_model* model, int op, const double* p, size_t P, si
 typedef enum inflx_path {
   INFLX_PATH_TILE = 0,       /* inflx_sweep_tile_*: some model value depends on x[1]                    */
   INFLX_PATH_ROW_STREAM = 1, /* inflx_sweep_rowvals_* + inflx_sweep_rowstream6/_planes (row-only model) */
-  INFLX_PATH_ROWS = 2        /* inflx_sweep_rows_*: row-only model, result shape the streams do not cover */
+  INFLX_PATH_ROWS = 2,       /* inflx_sweep_rows_*: row-only model, result shape the streams do not cover */
+  INFLX_PATH_COL_STREAM = 3  /* inflx_sweep_colvals_* + inflx_sweep_colstream (no value depends on x[0])      */
 } inflx_path;
 int inflx_sweep_plan(const inflx_model* model, int op, size_t P, size_t N1, size_t row_count, int layout, uint32_t plan[4]);
 

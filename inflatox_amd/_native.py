@@ -353,10 +353,10 @@ class InflatoxDevLib:
         return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 
     def sweep_plan(self, op, P, N1, row_count, layout=LAYOUT_AOS) -> dict:
-        """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows", "batch_rows", "batches", "replicas"}``."""
+        """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows"|"col_stream", "batch_rows", "batches", "replicas"}``."""
         plan = (C.c_uint32 * 4)()
         _check(self._lib.inflx_sweep_plan(self._h, op, P, N1, row_count, layout, plan))
-        return {"path": ("tile", "row_stream", "rows")[plan[0]], "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
+        return {"path": ("tile", "row_stream", "rows", "col_stream")[plan[0]], "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))

@@ -175,6 +175,9 @@ struct inflx_model {
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
   hipFunction_t rowstream_planes = nullptr;
+  hipFunction_t colvals[INFLX_OP_COUNT] = {};  // column-broadcast path: one row image per launch ...
+  hipFunction_t colstream = nullptr;           // ... copied into every grid row
+  hipFunction_t colvals_stats = nullptr;
   hipFunction_t tile_stats = nullptr, tile_stats_nostore = nullptr, rowvals_stats = nullptr;
   double* d_stats = nullptr;  // 18 x 8 bytes: min[6], max[6], count[6]
   // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
@@ -308,6 +311,20 @@ bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   return aos6 || planes;
 }
 
+// does this sweep take the two-launch column-broadcast path (row image + copy stream)?  No model value depends on
+// x[0], and an output row is a whole number of 16-byte units.
+bool takes_col_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
+  if ((m->info.out_mask & 3u) != 2u || op == INFLX_OP_QDIF) return false;
+  const size_t K = kOpWidth[op];
+  const bool planes = layout == INFLX_SOA || K == 1;
+  if (planes) return N1 % 2 == 0 && P * K <= 65535;
+  return (K * N1) % 2 == 0 && P <= 65535;
+}
+// the per-row / per-column evaluation of the broadcast paths runs on the side stream and is what reads the parameters
+bool evaluates_on_side_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
+  return takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1);
+}
+
 // Geometry of the two-launch row-broadcast path for one call (shared by launch_grid and inflx_sweep_plan).
 struct RowStreamPlan {
   size_t cpr;       // workgroups (4 KiB pieces) per grid row
@@ -401,6 +418,49 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
           const size_t nr = std::min<size_t>(65535, row_count - r0);
           HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
                                         (unsigned)(aos6 ? pb : pb * K), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+        }
+        HIP_TRY(hipEventRecord(m->table_free[b], s));
+        m->table_used[b] = true;
+      }
+    }
+  } else if (takes_col_stream(m, op, layout, P, N1)) {
+    // two launches: the image of one output row per parameter row (and plane) into the table, then the copy stream
+    const size_t K = kOpWidth[op];
+    const bool planes = layout == INFLX_SOA || K == 1;
+    const size_t images_per_p = planes ? K : 1;
+    const size_t units = (planes ? N1 : K * N1) / 2;  // 16-byte units per output row
+    const size_t cpr = (units + m->info.tile_cols - 1) / m->info.tile_cols;
+    if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
+    const size_t image_doubles = K * N1;  // per parameter row
+    size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(image_doubles * 8, 1)));
+    batch = std::min<size_t>(batch, 65535 / images_per_p);
+    if (what == 2 && batch < P)
+      return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
+    const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
+    for (size_t p0 = 0; p0 < P; p0 += batch) {
+      const size_t pb = std::min(batch, P - p0);
+      const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
+      const bool store = d_out != nullptr;
+      int rc = store ? ensure_row_table(m, b, pb * image_doubles) : INFLX_OK;
+      if (rc) return rc;
+      a.params = d_params + p0 * m->n_par;
+      a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;
+      a.P = (uint32_t)pb;
+      a.row_table = store ? m->d_row_table[b] : nullptr;
+      a.stream_units = units;
+      if (what != 2) {
+        if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+        HIP_TRY(hipModuleLaunchKernel(d_stats ? m->colvals_stats : m->colvals[op], (unsigned)gx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params,
+                                      nullptr));
+        HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+        m->table_turn++;
+      }
+      if (what != 1 && store) {
+        HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+        for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
+          a.stream_row0 = (uint32_t)r0;
+          const size_t nr = std::min<size_t>(65535, row_count - r0);
+          HIP_TRY(hipModuleLaunchKernel(m->colstream, (unsigned)cpr, (unsigned)nr, (unsigned)(pb * images_per_p), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
         }
         HIP_TRY(hipEventRecord(m->table_free[b], s));
         m->table_used[b] = true;
@@ -620,8 +680,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
       }
     }
     const std::string rv = std::string("inflx_sweep_rowvals_") + kOpNames[op];
-    if (hipModuleGetFunction(&m->rowvals[op], m->module, rv.c_str()) != hipSuccess) {
-      fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s", artefact_path, rv.c_str());
+    const std::string cv = std::string("inflx_sweep_colvals_") + kOpNames[op];
+    if (hipModuleGetFunction(&m->rowvals[op], m->module, rv.c_str()) != hipSuccess ||
+        hipModuleGetFunction(&m->colvals[op], m->module, cv.c_str()) != hipSuccess) {
+      fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s / %s", artefact_path, rv.c_str(), cv.c_str());
       return bail(INFLX_ERR_SYMBOL);
     }
   }
@@ -629,7 +691,9 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
       hipModuleGetFunction(&m->tile_stats, m->module, "inflx_sweep_tile_complete_stats") != hipSuccess ||
       hipModuleGetFunction(&m->tile_stats_nostore, m->module, "inflx_sweep_tile_complete_stats_nostore") != hipSuccess ||
       hipModuleGetFunction(&m->rowvals_stats, m->module, "inflx_sweep_rowvals_complete_stats") != hipSuccess ||
-      hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess) {
+      hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess ||
+      hipModuleGetFunction(&m->colstream, m->module, "inflx_sweep_colstream") != hipSuccess ||
+      hipModuleGetFunction(&m->colvals_stats, m->module, "inflx_sweep_colvals_complete_stats") != hipSuccess) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
@@ -716,6 +780,8 @@ int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t r
     plan[1] = (uint32_t)r.batch;
     plan[2] = (uint32_t)((P + r.batch - 1) / r.batch);
     plan[3] = (uint32_t)r.replicas;
+  } else if (takes_col_stream(m, op, layout, P, N1)) {
+    plan[0] = INFLX_PATH_COL_STREAM;
   } else if ((m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF) {
     plan[0] = INFLX_PATH_ROWS;
   } else {
@@ -735,7 +801,7 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
     return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, P * row_count * N1 * kOpBytes[op]);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  const bool row_path = takes_row_stream(m, op, INFLX_AOS, P, N1);
+  const bool row_path = evaluates_on_side_stream(m, op, INFLX_AOS, P, N1);
   hipStream_t eval = row_path ? m->side : s;  // the stream of the kernels that accumulate
   if (!m->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), 18 * sizeof(double)));
   inflx_summary init;
@@ -781,7 +847,7 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
   // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
   // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
-  hipStream_t reader = takes_row_stream(m, op, layout, P, N1) ? m->side : s;
+  hipStream_t reader = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
   if ((rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s))) return rc;
@@ -796,7 +862,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
   if (rc) return rc;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  hipStream_t reader = takes_row_stream(m, op, layout, P, N1) ? m->side : s;
+  hipStream_t reader = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
   const double* d_params = m->pslot[m->pcur].dev;  // what the call above uploaded (or found in place)
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipEventRecord(m->t0, s));
@@ -927,7 +993,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   }
   // the stream of the kernels that read the parameters: decided by the P the launches below really see (the
   // whole-result path launches all P rows at once, the chunk pipeline one parameter row at a time)
-  hipStream_t reader = takes_row_stream(m, op, layout, whole ? P : 1, N1) ? m->side : m->stream;
+  hipStream_t reader = evaluates_on_side_stream(m, op, layout, whole ? P : 1, N1) ? m->side : m->stream;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
   if (whole) {

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 11u
+#define INFLX_KERNEL_ABI 12u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -51,6 +51,10 @@ struct InflxSweepArgs {
   // *_stats kernels: running summary of the six outputs over everything the launch evaluates --
   // [0..5] NaN-ignoring minimum, [6..11] NaN-ignoring maximum (f64), [12..17] number of non-NaN values (u64)
   double* stats;
+  // column-broadcast path (no model value depends on x[0]): row_table holds the image of ONE output row per
+  // image index z -- AOS: z = parameter row, stream_units = K*N1/2; planes: z = p*K + k, stream_units = N1/2 --
+  // and inflx_sweep_colstream copies image z into every grid row: out unit ((z*row_count + row)*stream_units + u)
+  uint64_t stream_units;  // 16-byte units per output row
 };
 
 // Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch

@@ -25,6 +25,10 @@
 //    HBM roofline prices (7.0-7.1 TB/s measured).  inflx_sweep_rows_* is the fallback for result
 //    shapes the stream kernels do not cover (odd N1 planes, the 5-value AoS diagnostic).
 //
+//  * column-broadcast path, used when no model value depends on x[0]: inflx_sweep_colvals_* evaluates the image of
+//    one output row (one lane per grid column), inflx_sweep_colstream copies it into every grid row -- the same
+//    store-stream shape, fed by an L2-resident 16-byte load per thread.
+//
 //  * inflx_sweep_traj_*: explicit point lists (src/anguelova.rs:633-977), one thread per point.
 //
 // Numerics: IEEE-strict FP64 (no fast-math, denormals kept, correctly rounded div/sqrt).
@@ -524,6 +528,63 @@ __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
 }
 
 // ================================================================================================
+// column kernels: no model value depends on x[0]  ->  one evaluation per grid column; every grid row is the
+// same image, which a store stream copies row by row (the mirror image of the row-broadcast path)
+// ================================================================================================
+template <int OP, bool STATS = false>
+__device__ __forceinline__ void sweep_colvals(const InflxSweepArgs& a) {
+  constexpr int K = OpWidth<OP>::K;
+  const uint64_t j = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  const unsigned p = blockIdx.y;
+  const bool in_range = j < a.N1;
+  double o[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) o[k] = 0.0;
+  if (in_range) {
+    double A[kNP];
+    load_params(a.params, p, A);
+    double U[kNU], R[kNR], C[kNC];
+    inflx_stage_uniform(A, U);
+    const double x0 = inflx_coord(a.row_begin, a.dx0, a.x0a);  // any row: by construction nothing below depends on it
+    const double x1 = inflx_coord(j, a.dx1, a.x1a);
+    inflx_stage_row(x0, A, U, R);
+    inflx_stage_col(x1, A, U, C);
+    InflxModelValues mv;
+    inflx_stage_point(x0, x1, A, U, R, C, mv);
+    apply_op<OP>(mv, o, a.accuracy);
+  }
+  if constexpr (STATS) {
+    // every grid row of this column has these six values: the column counts row_count times
+    StatAcc acc;
+    stat_init(acc);
+    if (in_range) stat_add(acc, o, a.row_count);
+    stat_flush(acc, a.stats);
+    if (a.row_table == nullptr) return;  // summary-only sweep
+  }
+  if (!in_range) return;
+  if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) a.row_table[((uint64_t)p * K + k) * a.N1 + j] = o[k];
+  } else {
+#pragma unroll
+    for (int k = 0; k < K; ++k) a.row_table[((uint64_t)p * a.N1 + j) * K + k] = o[k];
+  }
+}
+
+// grid: x = 4 KiB piece of the row image, y = grid row (relative to stream_row0), z = image.  One 16-byte load
+// (the image stays in L2: at most a few hundred KiB, read once per grid row) and one 16-byte non-temporal store per
+// thread -- the shape of inflx_sweep_rowstream6.
+__device__ __forceinline__ void sweep_colstream(const InflxSweepArgs& a) {
+  const uint64_t u = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  const uint64_t row = (uint64_t)a.stream_row0 + blockIdx.y;
+  const uint64_t z = blockIdx.z;
+  if (u < a.stream_units) {
+    const inflx_d2 v = reinterpret_cast<const inflx_d2*>(a.row_table)[z * a.stream_units + u];
+    __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(a.out) + (z * a.row_count + row) * a.stream_units + u);
+  }
+}
+
+// ================================================================================================
 // on-trajectory kernels: explicit (n,2) point list (src/anguelova.rs:633-977)
 // ================================================================================================
 template <int OP>
@@ -558,6 +619,9 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowvals_##NAME(const InflxSweepArgs a) { \
     if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rowvals<OP>(a);                                       \
   }                                                                                                      \
+  extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colvals_##NAME(const InflxSweepArgs a) { \
+    if constexpr ((INFLX_OUT_MASK & 3) == 2) sweep_colvals<OP>(a);                                       \
+  }                                                                                                      \
   extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_traj_##NAME(const InflxTrajectoryArgs a) { \
     sweep_trajectory<OP>(a);                                                                             \
   }
@@ -588,6 +652,10 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowvals_compl
 }
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream_planes(const InflxSweepArgs a) {
   sweep_rowstream_planes(a);
+}
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colstream(const InflxSweepArgs a) { sweep_colstream(a); }
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colvals_complete_stats(const InflxSweepArgs a) {
+  if constexpr ((INFLX_OUT_MASK & 3) == 2) sweep_colvals<INFLX_OP_COMPLETE, true>(a);
 }
 
 INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)

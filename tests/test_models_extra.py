@@ -96,3 +96,65 @@ def test_gpu_matches_oracle(name, gpu_lib):
         tol.check(got, want, allowed, None, f"{name}/{n0}x{n1}")
         got_raw = lib.sweep_host(gpu_lib.OP_RAW, args, ext, n0, n1)
         compare(got_raw, raw, 1e-10, f"{name}/raw")
+
+
+@pytest.mark.gpu
+def test_column_only_model_takes_the_column_broadcast_path(gpu_lib):
+    """No model value depends on x[0]: one row image per parameter row (inflx_sweep_colvals_*) copied into every grid
+    row (inflx_sweep_colstream).  Whatever the shape, row range, batch, layout and operation, element [p, i, j] is bit
+    for bit what the on-trajectory kernel computes at that point; shapes whose rows are not whole 16-byte units fall
+    back to the tile kernels."""
+    import torch
+
+    model, args, ext, om, comp, hdr, symdict = setup("column_only")
+    art = Compiler(model, silent=True).compile()
+    lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    assert lib.stage_info["out_mask"] == 2
+    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, 3, 300, 64)["path"] == "col_stream"
+    assert lib.sweep_plan(gpu_lib.OP_RAW, 1, 301, 64)["path"] == "tile"  # 5 x 301 doubles per row: not whole 16-byte units
+    assert lib.sweep_plan(gpu_lib.OP_EPSILON_V, 1, 301, 64)["path"] == "tile"
+    rng = np.random.default_rng(77)
+    x0a, x0b, x1a, x1b = ext
+    ops = [(gpu_lib.OP_COMPLETE, 6), (gpu_lib.OP_CONSISTENCY, 1), (gpu_lib.OP_RAW, 5), (gpu_lib.OP_EPSILON_V, 1)]
+    shapes = [(1, 1), (1, 258), (300, 2), (2, 2), (33, 255), (32, 256), (31, 514), (97, 64), (5, 1026), (70000, 6)]
+    for case in range(30):
+        n0, n1 = shapes[case] if case < len(shapes) else (int(rng.integers(1, 200)), int(rng.integers(1, 900)))
+        P = int(rng.integers(1, 4))
+        op, k = ops[case % len(ops)]
+        layout = gpu_lib.LAYOUT_SOA if (case // 2) % 2 else gpu_lib.LAYOUT_AOS
+        rb = int(rng.integers(0, n0))
+        rc = int(rng.integers(1, n0 - rb + 1))
+        rows = np.stack([args * (1.0 + 0.03 * q) for q in range(P)])
+        ss = np.array([[x0a, x0b], [x1a, x1b]])
+        dx0, dx1 = (x0b - x0a) / n0, (x1b - x1a) / n1
+        xs0 = np.arange(rb, rb + rc, dtype=np.float64) * dx0 + x0a
+        xs1 = np.arange(n1, dtype=np.float64) * dx1 + x1a
+        # the values do not depend on x0: the trajectory needs one row only
+        pts = np.column_stack([np.full(n1, xs0[0]), xs1])
+        one = np.stack([lib.sweep_on_trajectory(op, rows[q], pts).reshape(n1, k) for q in range(P)])  # (P, n1, k)
+        want = np.broadcast_to(one[:, None], (P, rc, n1, k))
+        if layout == gpu_lib.LAYOUT_SOA:
+            want = np.moveaxis(want, -1, 1)
+        got = lib.sweep_host(op, rows, ss, n0, n1, row_begin=rb, row_count=rc, layout=layout)
+        what = (case, n0, n1, P, op, layout, rb, rc, lib.sweep_plan(op, P, n1, rc, layout)["path"])
+        assert np.array_equal(got.reshape(want.shape), want, equal_nan=True), what
+    # against the oracle, and the summary of the column path (weight = number of rows)
+    n0, n1 = 301, 518
+    got = lib.sweep_host(gpu_lib.OP_COMPLETE, args, ext, n0, n1)
+    want = om.grid_sweep(oracle.OP.COMPLETE, args, ext, n0, n1)
+    compare(got, want, 1e-9, "column_only/301x518")
+    from inflatox_amd.distributed import numpy_summary
+
+    stats, ref = lib.sweep_stats(args, ext, n0, n1), numpy_summary(got)
+    assert np.array_equal(stats["count"], ref["count"]) and np.array_equal(stats["min"], ref["min"]) and np.array_equal(stats["max"], ref["max"])
+    # full size, device-resident: every row equals row 0; store-stream speed
+    n = 8192
+    out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    ms = lib.sweep_device_timed(gpu_lib.OP_COMPLETE, args, out.data_ptr(), out.numel() * 8, ext, n, n, repeats=20)
+    torch.cuda.synchronize()
+    row0 = out[:1]
+    assert bool(((out == row0) | (torch.isnan(out) & torch.isnan(row0))).all())
+    compare(row0[0].cpu().numpy(), om.grid_sweep(oracle.OP.COMPLETE, args, ext, 1, n)[0], 1e-9, "column_only/8192 row 0")
+    print(f"column-broadcast sweep 8192^2: {ms:.3f} ms = {48 * n * n / ms / 1e9:.2f} TB/s")
+    assert 48 * n * n / (ms * 1e-3) > 4.0e12  # HBM-write-bound like the row path (tile kernels: ~3e12)
