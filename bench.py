@@ -28,7 +28,6 @@ host cores.
 from __future__ import annotations
 
 import argparse
-import hashlib
 import json
 import os
 import subprocess
@@ -57,9 +56,11 @@ def host_threads() -> int:
     return n
 
 
-def code_object_id(path: str) -> str:
-    """What identifies the kernels a profile was taken of: the first 16 hex digits of the code object's SHA-256."""
-    return hashlib.sha256(open(path, "rb").read()).hexdigest()[:16]
+def code_object_id(art) -> str:
+    """What identifies the kernels a profile was taken of: the content tag of the artefact in the in-tree cache
+    (SHA-256 over the generated model header, the kernel sources and the compiler flags -- the name the code object
+    is cached under).  Deterministic, unlike the bytes of the code object, which embed the build path."""
+    return os.path.splitext(os.path.basename(art.header_path))[0]
 
 
 def recorded(kind: str, key: str, code_id: str):
@@ -147,7 +148,7 @@ def secondary_workloads(_native, workloads, torch, np, device, stream):
             # transient and reads 10-15 % slow
             ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
             pps = P * n * n / (ms * 1e-3)
-            cid = code_object_id(art.shared_object_path)
+            cid = code_object_id(art)
             valu, src = recorded("valu", name, cid)
             rec = {
                 "workload": text,
@@ -237,6 +238,13 @@ def main():
     if distributed:
         import torch.distributed as dist
 
+        if world == 1 and "RANK" not in os.environ:  # INFLX_BENCH_FORCE_DIST=1 without a launcher: a one-rank rendezvous of our own
+            import socket
+
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port = sock.getsockname()[1]
+            os.environ.update(RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         # RCCL announces itself on stdout ("Librccl path : ..."); stdout carries the one JSON line only,
         # so point fd 1 at stderr while the process group comes up
         sys.stdout.flush()
@@ -345,7 +353,7 @@ def main():
 
     if rank == 0:
         kernel = "inflx_sweep_rowstream6" if row_path else "inflx_sweep_tile_complete"
-        cid = code_object_id(art.shared_object_path)
+        cid = code_object_id(art)
         traffic_rec, traffic_src = recorded("traffic", kernel, cid) if (opt.model, opt.n) == ("hyperbolic", 8192) else (None, None)
         line = {
             "metric": "grid-points/sec on complete_analysis sweep; achieved HBM GB/s vs peak",

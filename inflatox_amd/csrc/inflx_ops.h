@@ -26,30 +26,38 @@ struct InflxModelValues {
 // handling, the Payne-Hanek branch for |x| >= 2^30, the infinity test.  Bit for bit OCML's results on that domain
 // (tests/test_epilogue_math_gpu.py compares them on the device); NaN in, NaN out.  The host twin keeps libm.
 #ifndef INFLX_HOST_TWIN
+// One Horner step.  (Measured on MI355X, A/B in one session, scripts/hoist_experiment.py: spelling the step as inline
+// `v_fma_f64` with the coefficient in a scalar register pair -- which avoids the v_mov_b64 + v_fmac_f64 pairs the
+// compiler emits where registers are short, D5: 32 of them -- costs s_mov/s_nop hazard slots instead and is not
+// faster overall: D5 0.505 / EGNO 0.453 / doc 0.244 / angular 0.279 ms against 0.497 / 0.435 / 0.244 / 0.289 as
+// written here; with the coefficient pinned in a vector register 0.484 / 0.442 / 0.245 / 0.287.  Within the noise:
+// the plain form stays.)
+INFLX_FN double inflx_horner(double s, double acc, double coefficient) { return __builtin_fma(s, acc, coefficient); }
+
 INFLX_FN double inflx_atan_nonneg(double t) {
 #pragma clang fp contract(off)
   const bool big = t > 1.0;
   const double x = big ? 1.0 / t : t;
   const double s = x * x;
   double p = __builtin_fma(s, 0x1.ba404b5e68a13p-17, -0x1.3e260bd3237f4p-13);
-  p = __builtin_fma(s, p, 0x1.b2bb069efb384p-11);
-  p = __builtin_fma(s, p, -0x1.7952daf56de9bp-9);
-  p = __builtin_fma(s, p, 0x1.d6d43a595c56fp-8);
-  p = __builtin_fma(s, p, -0x1.c6ea4a57d9582p-7);
-  p = __builtin_fma(s, p, 0x1.67e295f08b19fp-6);
-  p = __builtin_fma(s, p, -0x1.e9ae6fc27006ap-6);
-  p = __builtin_fma(s, p, 0x1.2c15b5711927ap-5);
-  p = __builtin_fma(s, p, -0x1.59976e82d3ff0p-5);
-  p = __builtin_fma(s, p, 0x1.82d5d6ef28734p-5);
-  p = __builtin_fma(s, p, -0x1.ae5ce6a214619p-5);
-  p = __builtin_fma(s, p, 0x1.e1bb48427b883p-5);
-  p = __builtin_fma(s, p, -0x1.110e48b207f05p-4);
-  p = __builtin_fma(s, p, 0x1.3b13657b87036p-4);
-  p = __builtin_fma(s, p, -0x1.745d119378e4fp-4);
-  p = __builtin_fma(s, p, 0x1.c71c717e1913cp-4);
-  p = __builtin_fma(s, p, -0x1.2492492376b7dp-3);
-  p = __builtin_fma(s, p, 0x1.99999999952ccp-3);
-  p = __builtin_fma(s, p, -0x1.5555555555523p-2);
+  p = inflx_horner(s, p, 0x1.b2bb069efb384p-11);
+  p = inflx_horner(s, p, -0x1.7952daf56de9bp-9);
+  p = inflx_horner(s, p, 0x1.d6d43a595c56fp-8);
+  p = inflx_horner(s, p, -0x1.c6ea4a57d9582p-7);
+  p = inflx_horner(s, p, 0x1.67e295f08b19fp-6);
+  p = inflx_horner(s, p, -0x1.e9ae6fc27006ap-6);
+  p = inflx_horner(s, p, 0x1.2c15b5711927ap-5);
+  p = inflx_horner(s, p, -0x1.59976e82d3ff0p-5);
+  p = inflx_horner(s, p, 0x1.82d5d6ef28734p-5);
+  p = inflx_horner(s, p, -0x1.ae5ce6a214619p-5);
+  p = inflx_horner(s, p, 0x1.e1bb48427b883p-5);
+  p = inflx_horner(s, p, -0x1.110e48b207f05p-4);
+  p = inflx_horner(s, p, 0x1.3b13657b87036p-4);
+  p = inflx_horner(s, p, -0x1.745d119378e4fp-4);
+  p = inflx_horner(s, p, 0x1.c71c717e1913cp-4);
+  p = inflx_horner(s, p, -0x1.2492492376b7dp-3);
+  p = inflx_horner(s, p, 0x1.99999999952ccp-3);
+  p = inflx_horner(s, p, -0x1.5555555555523p-2);
   const double a = __builtin_fma(x, s * p, x);
   // pi/2 - a, with pi/2 as the product OCML uses (0x1.dd9ad336a0500p-1 * 0x1.af154eeb562d6p+0, one rounding)
   return big ? __builtin_fma(0x1.dd9ad336a0500p-1, 0x1.af154eeb562d6p+0, -a) : a;
@@ -72,18 +80,18 @@ INFLX_FN double inflx_tan_quadrant1(double x) {
   const double s0 = r * r;
   const double s = s0 + __builtin_fma(r, rr * 2.0, __builtin_fma(r, r, -s0));
   double p = __builtin_fma(s, 0x1.5e089c751c08cp-16, -0x1.78809a9a29f71p-15);
-  p = __builtin_fma(s, p, 0x1.7746f90a8aae0p-14);
-  p = __builtin_fma(s, p, -0x1.bb44da6fbf144p-16);
-  p = __builtin_fma(s, p, 0x1.1e634a7943acfp-13);
-  p = __builtin_fma(s, p, 0x1.d250fdeb68febp-13);
-  p = __builtin_fma(s, p, 0x1.37fd9b58c4d95p-11);
-  p = __builtin_fma(s, p, 0x1.7d5af15120e2cp-10);
-  p = __builtin_fma(s, p, 0x1.d6d93e09491dfp-9);
-  p = __builtin_fma(s, p, 0x1.226e12033784dp-7);
-  p = __builtin_fma(s, p, 0x1.664f49ac36ae2p-6);
-  p = __builtin_fma(s, p, 0x1.ba1ba1b451c21p-5);
-  p = __builtin_fma(s, p, 0x1.11111111185b7p-3);
-  p = __builtin_fma(s, p, 0x1.55555555554eep-2);
+  p = inflx_horner(s, p, 0x1.7746f90a8aae0p-14);
+  p = inflx_horner(s, p, -0x1.bb44da6fbf144p-16);
+  p = inflx_horner(s, p, 0x1.1e634a7943acfp-13);
+  p = inflx_horner(s, p, 0x1.d250fdeb68febp-13);
+  p = inflx_horner(s, p, 0x1.37fd9b58c4d95p-11);
+  p = inflx_horner(s, p, 0x1.7d5af15120e2cp-10);
+  p = inflx_horner(s, p, 0x1.d6d93e09491dfp-9);
+  p = inflx_horner(s, p, 0x1.226e12033784dp-7);
+  p = inflx_horner(s, p, 0x1.664f49ac36ae2p-6);
+  p = inflx_horner(s, p, 0x1.ba1ba1b451c21p-5);
+  p = inflx_horner(s, p, 0x1.11111111185b7p-3);
+  p = inflx_horner(s, p, 0x1.55555555554eep-2);
   const double u = s * p;
   const double e = r * u;
   const double el = __builtin_fma(r, u, -e);

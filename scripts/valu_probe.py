@@ -2,7 +2,6 @@
 """One complete_analysis sweep per example model (AoS, device-resident) -- the workload for the rocprofv3
 --pmc passes whose SQ counters scripts/valu_report.py turns into profiles/r01_valu.json.
 usage: valu_probe.py [MODEL:N ...]"""
-import hashlib
 import json
 import os
 import sys
@@ -21,7 +20,7 @@ for name, n in cases:
     n = int(n)
     spec, art = workloads.artifact_for(name)
     lib = _native.InflatoxDevLib(art.shared_object_path)
-    stamps[name] = hashlib.sha256(open(art.shared_object_path, "rb").read()).hexdigest()[:16]  # bench.py code_object_id
+    stamps[name] = os.path.splitext(os.path.basename(art.header_path))[0]  # bench.py code_object_id: the cache tag
     out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
     for _ in range(2):
         lib.sweep_device(_native.OP_COMPLETE, np.asarray(spec.args), out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=stream)
