@@ -83,7 +83,8 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     import numpy as np
 
     import oracle
-    from inflatox_amd import example_models, workloads
+    import workloads
+    from workloads import example_models
 
     spec = example_models.get(model_name)
     src, _ = oracle.emit_c_source(workloads.model_for(model_name), **spec.compiler_kwargs)
@@ -262,7 +263,9 @@ def main():
             os.dup2(saved_stdout, 1)
             os.close(saved_stdout)
 
-    from inflatox_amd import _native, workloads
+    from inflatox_amd import _native
+
+    import workloads
     from inflatox_amd.distributed import plan_shard
 
     spec, art = workloads.artifact_for(opt.model)

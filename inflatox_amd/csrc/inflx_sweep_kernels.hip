@@ -230,7 +230,11 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   // wave-uniform values: computed once per workgroup, every later use is an LDS broadcast read, so
   // they cost no long-lived VGPRs (a uniform f64 cannot live in SGPRs: there is no scalar FP unit)
   __shared__ double U[kNU];
+#ifdef INFLX_EXPERIMENT_NO_PROLOGUE  // (timing experiment only: results are wrong)
+  if (tid < kNU) U[tid] = A[tid % kNP] + tid;
+#else
   if (tid == 0) inflx_stage_uniform(A, U);
+#endif
   __syncthreads();
 #else
   double U[kNU];
@@ -241,7 +245,11 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const uint64_t j = col0 + tid;
   const double x1 = inflx_coord(j, a.dx1, a.x1a);
   double C[kNC];
+#ifdef INFLX_EXPERIMENT_NO_PROLOGUE
+  for (int k = 0; k < kNC; ++k) C[k] = x1 * (k + 1.5);
+#else
   inflx_stage_col(x1, A, U, C);
+#endif
 
   // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
   const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * kTileRows;
@@ -249,7 +257,11 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
   if ((int)tid < nrows) {
     const double x0 = inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a);
+#ifdef INFLX_EXPERIMENT_NO_PROLOGUE
+    for (int k = 0; k < kNR; ++k) Rs[tid][k] = x0 * (k + 0.5) + 1.0;
+#else
     inflx_stage_row(x0, A, U, Rs[tid]);
+#endif
   }
   __syncthreads();
 

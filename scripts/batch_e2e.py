@@ -3,7 +3,7 @@ import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 sys.path.insert(0, os.path.join(os.environ.get("GRAFT_REPO_ROOT", "/root/repo"), "tests"))
 from conftest import generalised_al
-from inflatox_amd import workloads
+import workloads
 spec, art = workloads.artifact_for("d5")
 al = generalised_al(art)
 P, n = 8, 4096

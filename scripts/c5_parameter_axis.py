@@ -22,7 +22,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import _native, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
 from inflatox_amd.distributed import all_reduce_summary, plan_shard  # noqa: E402
 
 

@@ -8,7 +8,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import workloads  # noqa: E402
+import workloads  # noqa: E402
 from inflatox_amd.consistency_conditions import GeneralisedAL  # noqa: E402
 
 for name, n in (("hyperbolic", 4096), ("hyperbolic", 8192), ("d5", 4096)):

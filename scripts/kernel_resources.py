@@ -10,7 +10,8 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import example_models, workloads  # noqa: E402
+import workloads  # noqa: E402
+from workloads import example_models  # noqa: E402
 from inflatox_amd.compiler import Compiler  # noqa: E402
 
 OBJDUMP = "/opt/rocm/lib/llvm/bin/llvm-objdump"

@@ -8,7 +8,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import _native, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
 
 cases = [("hyperbolic", 8192, 1), ("hyperbolic", 1024, 1), ("doc", 4096, 1), ("angular", 4096, 1), ("egno", 4096, 1), ("d5", 4096, 1), ("d5", 2048, 4)]
 if len(sys.argv) > 1:

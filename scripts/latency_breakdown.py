@@ -1,7 +1,7 @@
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-from inflatox_amd import workloads
+import workloads
 from inflatox_amd.consistency_conditions import GeneralisedAL
 spec, art = workloads.artifact_for("hyperbolic")
 al = GeneralisedAL(art)

@@ -9,7 +9,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import workloads  # noqa: E402
+import workloads  # noqa: E402
 from inflatox_amd.consistency_conditions import GeneralisedAL  # noqa: E402
 
 for name in sys.argv[1:] or ["hyperbolic", "doc", "d5"]:

@@ -9,7 +9,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import _native, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
 
 name = sys.argv[1] if len(sys.argv) > 1 else "egno"
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 4096

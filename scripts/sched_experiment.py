@@ -7,7 +7,9 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import _native, example_models, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
+from workloads import example_models  # noqa: E402
 from inflatox_amd.compiler import Compiler  # noqa: E402
 
 n = 4096

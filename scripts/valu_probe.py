@@ -11,7 +11,8 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from inflatox_amd import _native, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
 
 cases = [a.split(":") for a in sys.argv[1:]] or [["hyperbolic", "8192"], ["doc", "4096"], ["angular", "4096"], ["egno", "4096"], ["d5", "4096"]]
 stream = torch.cuda.current_stream().cuda_stream

@@ -28,7 +28,8 @@ def golden(name):
 def oracle_model(name):
     """The CPU oracle for an example model: this repo's symbolic stage -> oracle C emitter -> gcc."""
     import oracle
-    from inflatox_amd import example_models, workloads
+    import workloads
+    from workloads import example_models
 
     spec = example_models.get(name)
     src, symdict = oracle.emit_c_source(workloads.model_for(name), **spec.compiler_kwargs)

@@ -10,7 +10,7 @@ Pipeline:
      ``inflatox.version``, ``inflatox.libinflx_rs`` as names that raise when called);
   2. run the reference's ``InflationModelBuilder.new(...).build(...)`` and
      ``Compiler(...)._generate_c_file()`` on the model definitions of
-     ``inflatox_amd/example_models.py`` (the models of the reference's README/tests);
+     ``workloads/example_models.py`` (the models of the reference's README/tests);
   3. compile the reference-emitted C with gcc and the reference's flag list (into a temp dir);
   4. evaluate it through oracle/sweep_oracle.c (the C restatement of the Rust sweep) on small
      grids, adversarial points included, and store numbers only:
@@ -135,7 +135,7 @@ GRIDS = {
 def main(models):
     import joblib
 
-    from inflatox_amd import example_models
+    from workloads import example_models
     from oracle import OP, OracleModel
     from oracle.model_c import REFERENCE_FLAGS
 
@@ -228,7 +228,7 @@ def basis_goldens(models):
 
     import joblib
 
-    from inflatox_amd import example_models
+    from workloads import example_models
     from oracle.cpu_oracle import basis_on_points
     from oracle.model_c import REFERENCE_FLAGS
 

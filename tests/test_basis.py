@@ -12,7 +12,8 @@ from oracle import cpu_oracle
 
 from conftest import GOLDEN_DIR, MODELS, oracle_model
 from host_twin import HostTwin
-from inflatox_amd import example_models, workloads
+import workloads
+from workloads import example_models
 from inflatox_amd.compiler import Compiler
 
 BASIS = dict(np.load(os.path.join(GOLDEN_DIR, "basis.npz")))

@@ -44,7 +44,7 @@ def test_open_fails_loudly_without_artefact_or_device():
     with pytest.raises(IOError):
         _native.InflatoxDevLib("/nonexistent/model.hsaco")
     if _native.device_count() == 0:
-        from inflatox_amd import workloads
+        import workloads
 
         _, art = workloads.artifact_for("hyperbolic")
         with pytest.raises(SystemError):
@@ -56,7 +56,7 @@ def test_code_object_exports_the_model_abi():
     import shutil
     import subprocess
 
-    from inflatox_amd import workloads
+    import workloads
 
     readelf = shutil.which("llvm-readelf") or "/opt/rocm/lib/llvm/bin/llvm-readelf"
     if not os.path.exists(readelf):

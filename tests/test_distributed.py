@@ -43,7 +43,8 @@ def _worker(rank, world, port, case, tmpdir):
     import torch.distributed as dist
 
     import oracle
-    from inflatox_amd import example_models, workloads
+    import workloads
+    from workloads import example_models
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     try:
@@ -99,7 +100,9 @@ def _gpu_worker(rank, world, port, case, tmpdir):
     import torch
     import torch.distributed as dist
 
-    from inflatox_amd import _native, workloads
+    from inflatox_amd import _native
+
+    import workloads
     from inflatox_amd.distributed import HipCompute
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)

@@ -45,7 +45,7 @@ _libs = {}
 
 def devlib(name, gpu_lib):
     if name not in _libs:
-        from inflatox_amd import workloads
+        import workloads
 
         spec, art = workloads.artifact_for(name)
         _libs[name] = (spec, art, gpu_lib.InflatoxDevLib(art.shared_object_path))
@@ -105,7 +105,7 @@ def test_matches_oracle_on_fresh_grid(name, gpu_lib):
 def test_drop_in_front_end(gpu_lib):
     """GeneralisedAL(...).complete_analysis signature/return contract + the reference's known answers
     (tests/test_doc.py:50-58)."""
-    from inflatox_amd import workloads
+    import workloads
     from inflatox_amd.consistency_conditions import GeneralisedAL
 
     spec, art = workloads.artifact_for("doc")
@@ -270,7 +270,7 @@ def test_flag_quantum_dif(name, gpu_lib):
 
 def test_array_helpers(gpu_lib):
     """calc_V_array / calc_H_array (reference consistency_conditions.py:67-156) vs the oracle's raw values."""
-    from inflatox_amd import workloads
+    import workloads
     from inflatox_amd.consistency_conditions import GeneralisedAL
 
     spec, art = workloads.artifact_for("doc")
@@ -565,7 +565,9 @@ def _defective(kind):
     """The README hyperbolic model with its second basis vector spoiled after the symbolic stage."""
     import copy
 
-    from inflatox_amd import Compiler, workloads
+    from inflatox_amd import Compiler
+
+    import workloads
 
     model = copy.copy(workloads.model_for("hyperbolic"))
     v, w = [list(vec) for vec in model.basis]
@@ -727,7 +729,7 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
     """Compiler(hoist_reciprocals=True): quotients by row/column/sweep-only denominators through Markstein's
     step, irregular rows re-evaluated with IEEE divisions after the hot loop -- bit for bit the default
     program's results, singular lines and NaN regions included."""
-    from inflatox_amd import workloads
+    import workloads
 
     spec, art0 = workloads.artifact_for(name, hoist_reciprocals=False)
     lib = gpu_lib.InflatoxDevLib(art0.shared_object_path)
@@ -847,7 +849,9 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     no torch in that process; results equal the ctypes path bit for bit, a shape error comes back as its status."""
     import subprocess
 
-    from inflatox_amd import _native, workloads
+    from inflatox_amd import _native
+
+    import workloads
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = tmp_path / "cabi_client"

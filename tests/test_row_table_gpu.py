@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(scope="module")
 def hyp(gpu_lib):
-    from inflatox_amd import workloads
+    import workloads
 
     spec, art = workloads.artifact_for("hyperbolic")
     lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
@@ -192,7 +192,7 @@ def test_back_to_back_tile_path_calls(gpu_lib):
     bit-equal to the same sweep issued alone."""
     import torch
 
-    from inflatox_amd import workloads
+    import workloads
 
     spec, art = workloads.artifact_for("doc")
     lib = gpu_lib.InflatoxDevLib(art.shared_object_path)

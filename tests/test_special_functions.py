@@ -15,7 +15,8 @@ import sympy
 
 from conftest import golden  # noqa: F401  (keeps the tests directory on sys.path)
 from host_twin import HostTwin
-from inflatox_amd import Compiler, InflationModelBuilder, example_models
+from inflatox_amd import Compiler, InflationModelBuilder
+from workloads import example_models
 from inflatox_amd.compiler import CInflatoxPrinter, GSLInflatoxPrinter
 from oracle import special
 

@@ -21,7 +21,7 @@ def _build(factory, name, **kw):
 
 
 def test_every_device_bessel_function_against_mpmath(gpu_lib):
-    from inflatox_amd import example_models
+    from workloads import example_models
     from inflatox_amd.consistency_conditions import InflationCondition
 
     model, comp, art = _build(example_models.bessel_probe, "bessel_probe", assertions=False, simplify=False)
@@ -50,7 +50,7 @@ def test_every_device_bessel_function_against_mpmath(gpu_lib):
 
 def test_bessel_model_sweep_against_scipy_stand_in(gpu_lib):
     from conftest import generalised_al
-    from inflatox_amd import example_models
+    from workloads import example_models
 
     model, comp, art = _build(example_models.bessel_toy, "bessel_toy")
     assert art.n_parameters == 2
@@ -79,7 +79,7 @@ def test_real_order_bessel_and_0F1_on_the_gpu(gpu_lib):
     """J_5/2, K_nu (nu a model parameter) and 0F1 inside a model: the raw values of a sweep against a
     30-digit mpmath evaluation of the same sympy expressions."""
     from conftest import generalised_al
-    from inflatox_amd import example_models
+    from workloads import example_models
 
     model, comp, art = _build(example_models.bessel_real, "bessel_real", assertions=False, simplify=False)
     al = generalised_al(art)
@@ -100,7 +100,7 @@ def test_hypergeometric_model_on_the_gpu(gpu_lib):
     against a 30-digit mpmath evaluation of the same sympy expressions; device-resident sweep included."""
     import torch
     from conftest import generalised_al
-    from inflatox_amd import example_models
+    from workloads import example_models
 
     model, comp, art = _build(example_models.hypergeometric, "hypergeometric", assertions=False, simplify=False)
     al = generalised_al(art)

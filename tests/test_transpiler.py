@@ -16,7 +16,8 @@ from conftest import GOLDEN_DIR, MODELS, compare, golden, oracle_model
 from host_twin import HostTwin
 
 import oracle
-from inflatox_amd import example_models, workloads
+import workloads
+from workloads import example_models
 from inflatox_amd.compiler import CInflatoxPrinter, CompilationArtifact, Compiler
 
 SYMBOLS = json.load(open(os.path.join(GOLDEN_DIR, "symbols.json")))

@@ -90,7 +90,8 @@ def single_quantities(raw: np.ndarray) -> dict:
 def _models(name):
     """(double oracle model, path of the long-double model object) for an example model."""
     import oracle
-    from inflatox_amd import example_models, workloads
+    import workloads
+    from workloads import example_models
 
     spec = example_models.get(name)
     m = workloads.model_for(name)

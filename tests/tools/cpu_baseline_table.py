@@ -8,7 +8,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 import oracle  # noqa: E402
 from bench import host_threads  # noqa: E402
-from inflatox_amd import example_models, workloads  # noqa: E402
+import workloads  # noqa: E402
+from workloads import example_models  # noqa: E402
 
 threads = host_threads()
 print(f"host threads used: {threads} (os.cpu_count() = {os.cpu_count()})")

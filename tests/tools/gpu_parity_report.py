@@ -11,7 +11,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
 import tolerance as tol  # noqa: E402
-from inflatox_amd import _native, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
 
 for name in sys.argv[1:] or ["hyperbolic", "doc", "angular", "egno", "d5"]:
     spec, art = workloads.artifact_for(name)

@@ -11,7 +11,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import oracle  # noqa: E402
 import tolerance as tol  # noqa: E402
-from inflatox_amd import _native, example_models, workloads  # noqa: E402
+from inflatox_amd import _native  # noqa: E402
+import workloads  # noqa: E402
+from workloads import example_models  # noqa: E402
 from inflatox_amd.compiler import Compiler  # noqa: E402
 
 n = 4096

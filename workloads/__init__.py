@@ -1,4 +1,5 @@
-"""Build-and-cache helpers for the named example models (used by build(), tests and bench.py).
+"""Workload definitions and build-and-cache helpers for the named example models -- inputs to the hot path, kept
+outside the ``inflatox_amd`` package (used by build(), bench.py, tests and scripts).
 
 ``artifact_for(name)`` runs the symbolic stage and the transpiler for one of
 ``example_models.ALL`` and returns ``(spec, CompilationArtifact)``.  The hipcc step is served from
@@ -11,9 +12,10 @@ from __future__ import annotations
 
 import functools
 
+from inflatox_amd.compiler import CompilationArtifact, Compiler
+from inflatox_amd.symbolic import InflationModel, InflationModelBuilder
+
 from . import example_models
-from .compiler import CompilationArtifact, Compiler
-from .symbolic import InflationModel, InflationModelBuilder
 
 
 @functools.lru_cache(maxsize=None)
