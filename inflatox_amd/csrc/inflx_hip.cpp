@@ -178,6 +178,16 @@ struct inflx_model {
   hipFunction_t colvals[INFLX_OP_COUNT] = {};  // column-broadcast path: one row image per launch ...
   hipFunction_t colstream = nullptr;           // ... copied into every grid row
   hipFunction_t colvals_stats = nullptr;
+  // tile path: stage tables (U per parameter row, R per grid row, C per grid column) written by inflx_stage_tables
+  // on the side stream, double-buffered like the row table: the tables of launch n+1 are evaluated while the tile
+  // kernel of launch n runs (the table kernel is a latency-bound chain on a few dozen workgroups)
+  hipFunction_t stage_tables = nullptr;
+  double* d_stage_tab[2] = {nullptr, nullptr};
+  size_t d_stage_tab_cap[2] = {0, 0};  // doubles
+  hipEvent_t stage_ready[2] = {nullptr, nullptr};  // inflx_stage_tables finished writing buffer b
+  hipEvent_t stage_free[2] = {nullptr, nullptr};   // the tile kernel that last read buffer b finished
+  bool stage_used[2] = {false, false};
+  unsigned stage_turn = 0;
   hipFunction_t tile_stats = nullptr, tile_stats_nostore = nullptr, rowvals_stats = nullptr;
   double* d_stats = nullptr;  // 18 x 8 bytes: min[6], max[6], count[6]
   // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
@@ -320,9 +330,18 @@ bool takes_col_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   if (planes) return N1 % 2 == 0 && P * K <= 65535;
   return (K * N1) % 2 == 0 && P <= 65535;
 }
-// the per-row / per-column evaluation of the broadcast paths runs on the side stream and is what reads the parameters
+// Which stream are the parameters uploaded on?  The first kernel that reads them runs on the side stream for the two
+// broadcast paths (per-row / per-column evaluation) and for the tile path (stage tables); only the fallback row kernel
+// of row-only models reads them on the caller's stream first.
 bool evaluates_on_side_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
-  return takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1);
+  if (takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1)) return true;
+  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
+  return !row_uniform;  // tile path
+}
+// ... and on which stream does the LAST kernel that reads them run?  The tile kernels read the parameter rows too
+// (the point stage uses args[k]), after the table kernel; on the broadcast paths the store streams do not.
+bool last_reader_is_callers_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
+  return !(takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1));
 }
 
 // Geometry of the two-launch row-broadcast path for one call (shared by launch_grid and inflx_sweep_plan).
@@ -485,12 +504,50 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
     if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch (%zu column tiles)", gx);
     if (row_count > 0xffffffffULL) return fail(INFLX_ERR_SHAPE, "at most 2^32 grid rows per call (got %zu)", row_count);
     hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
-    // grid.y is limited to 65535 tiles: taller slabs take several launches, each told its first slab row
+    // Stage tables: U[P][nu] | R[P][slab][nr] | C[P][nc][N1] doubles, written by inflx_stage_tables on the same stream
+    // right before the tile kernel that reads them.  grid.y is limited to 65535 tiles, so a taller slab takes several
+    // launches, each with tables of its own; parameter rows are batched so that one set of tables stays below 1 GiB.
+    const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nr = std::max<size_t>(m->info.n_row, 1), nc = std::max<size_t>(m->info.n_col, 1);
     const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
-    for (size_t r0 = 0; r0 < row_count; r0 += rows_per_launch) {
-      a.stream_row0 = (uint32_t)r0;
-      const size_t gy = (std::min(rows_per_launch, row_count - r0) + m->info.tile_rows - 1) / m->info.tile_rows;
-      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)P, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+    const size_t slab_max = std::min(rows_per_launch, row_count);
+    const size_t per_p = nu + slab_max * nr + nc * N1;  // doubles per parameter row
+    const size_t pbatch = std::max<size_t>(1, std::min<size_t>(P, (size_t(1) << 27) / std::max<size_t>(per_p, 1)));
+    const size_t K = kOpWidth[op];
+    for (size_t p0 = 0; p0 < P; p0 += pbatch) {
+      const size_t pb = std::min(pbatch, P - p0);
+      a.params = d_params + p0 * m->n_par;
+      a.out = d_out ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_out) + p0 * row_count * N1 * kOpBytes[op]) : nullptr;
+      a.P = (uint32_t)pb;
+      (void)K;
+      for (size_t r0 = 0; r0 < row_count; r0 += rows_per_launch) {
+        const size_t slab = std::min(rows_per_launch, row_count - r0);
+        const size_t need = pb * (nu + slab * nr + nc * N1);
+        const int b = (int)(m->stage_turn & 1);
+        if (need > m->d_stage_tab_cap[b]) {
+          // nothing may still be reading the old tables
+          if (m->stage_used[b]) HIP_TRY(hipEventSynchronize(m->stage_free[b]));
+          if (m->d_stage_tab[b]) HIP_TRY(hipFree(m->d_stage_tab[b]));
+          m->d_stage_tab[b] = nullptr;
+          m->d_stage_tab_cap[b] = 0;
+          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stage_tab[b]), need * sizeof(double)));
+          m->d_stage_tab_cap[b] = need;
+        }
+        a.row_table = m->d_stage_tab[b];
+        a.stream_row0 = (uint32_t)r0;
+        a.stream_units = slab;
+        // tables on the side stream, as soon as the tile kernel that read this buffer two launches ago is done ...
+        if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->stage_free[b], 0));
+        const size_t tx = (std::max(slab, N1) + m->info.tile_cols - 1) / m->info.tile_cols;
+        HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params, nullptr));
+        HIP_TRY(hipEventRecord(m->stage_ready[b], m->side));
+        m->stage_turn++;
+        // ... and the tile kernel on the caller's stream behind them
+        HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
+        const size_t gy = (slab + m->info.tile_rows - 1) / m->info.tile_rows;
+        HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+        HIP_TRY(hipEventRecord(m->stage_free[b], s));
+        m->stage_used[b] = true;
+      }
     }
   }
   return INFLX_OK;
@@ -697,6 +754,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
+  if (hipModuleGetFunction(&m->stage_tables, m->module, "inflx_stage_tables") != hipSuccess) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_stage_tables", artefact_path);
+    return bail(INFLX_ERR_SYMBOL);
+  }
   if (hipModuleGetFunction(&m->basis_points, m->module, "inflx_basis_points") != hipSuccess) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_basis_points", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
@@ -714,6 +775,13 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
         hipEventCreateWithFlags(&m->table_ready[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipEventCreateWithFlags(&m->table_free[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
         hipEventCreateWithFlags(&m->copy_done[k], hipEventDisableTiming) != hipSuccess) {
+      fail(INFLX_ERR_DEVICE, "could not create HIP events");
+      return bail(INFLX_ERR_DEVICE);
+    }
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (hipEventCreateWithFlags(&m->stage_ready[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess ||
+        hipEventCreateWithFlags(&m->stage_free[k], hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
       fail(INFLX_ERR_DEVICE, "could not create HIP events");
       return bail(INFLX_ERR_DEVICE);
     }
@@ -739,6 +807,11 @@ void inflx_close(inflx_model* m) {
     if (m->table_ready[k]) (void)hipEventDestroy(m->table_ready[k]);
     if (m->table_free[k]) (void)hipEventDestroy(m->table_free[k]);
     if (m->d_row_table[k]) (void)hipFree(m->d_row_table[k]);
+  }
+  for (int k = 0; k < 2; ++k) {
+    if (m->stage_ready[k]) (void)hipEventDestroy(m->stage_ready[k]);
+    if (m->stage_free[k]) (void)hipEventDestroy(m->stage_free[k]);
+    if (m->d_stage_tab[k]) (void)hipFree(m->d_stage_tab[k]);
   }
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
@@ -801,8 +874,11 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
     return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, P * row_count * N1 * kOpBytes[op]);
   HIP_TRY(hipSetDevice(m->device));
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  const bool row_path = evaluates_on_side_stream(m, op, INFLX_AOS, P, N1);
-  hipStream_t eval = row_path ? m->side : s;  // the stream of the kernels that accumulate
+  // `up`: the stream of the first kernel of the sweep (parameters and the initial summary are ordered before it);
+  // `eval`: the stream of the kernels that accumulate (the per-row / per-column evaluation of the broadcast paths on the
+  // side stream, the tile kernels on the caller's)
+  hipStream_t up = evaluates_on_side_stream(m, op, INFLX_AOS, P, N1) ? m->side : s;
+  hipStream_t eval = last_reader_is_callers_stream(m, op, INFLX_AOS, P, N1) ? s : m->side;
   if (!m->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), 18 * sizeof(double)));
   inflx_summary init;
   for (int k = 0; k < 6; ++k) {
@@ -811,9 +887,9 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
     init.count[k] = 0;
   }
   static_assert(sizeof(inflx_summary) == 18 * 8, "inflx_summary must match the device layout");
-  HIP_TRY(hipMemcpyAsync(m->d_stats, &init, sizeof init, hipMemcpyHostToDevice, eval));
+  HIP_TRY(hipMemcpyAsync(m->d_stats, &init, sizeof init, hipMemcpyHostToDevice, up));
   const double* d_params = nullptr;
-  if ((rc = acquire_params(m, p, P * n_p, eval, &d_params))) return rc;
+  if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   if (row_count && N1) {
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, INFLX_AOS, s, 0, 0.0, m->d_stats);
     if (rc) return rc;
@@ -847,11 +923,11 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
   // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
   // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
-  hipStream_t reader = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
+  hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
   const double* d_params = nullptr;
-  if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
+  if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   if ((rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s))) return rc;
-  return release_params(m, reader);
+  return release_params(m, last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side);
 }
 
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
@@ -862,7 +938,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
   if (rc) return rc;
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  hipStream_t reader = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
+  hipStream_t reader = last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side;
   const double* d_params = m->pslot[m->pcur].dev;  // what the call above uploaded (or found in place)
   HIP_TRY(hipStreamSynchronize(s));
   HIP_TRY(hipEventRecord(m->t0, s));

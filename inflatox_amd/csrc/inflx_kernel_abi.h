@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 12u
+#define INFLX_KERNEL_ABI 13u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -55,6 +55,9 @@ struct InflxSweepArgs {
   // image index z -- AOS: z = parameter row, stream_units = K*N1/2; planes: z = p*K + k, stream_units = N1/2 --
   // and inflx_sweep_colstream copies image z into every grid row: out unit ((z*row_count + row)*stream_units + u)
   uint64_t stream_units;  // 16-byte units per output row
+  // tile kernels (some value depends on x[1]): row_table holds the stage tables inflx_stage_tables wrote for this launch,
+  //   U[P][max(NU,1)] | R[P][slab_rows][max(NR,1)] | C[P][max(NC,1)][N1]   (doubles),
+  // the slab being grid rows [stream_row0, stream_row0 + stream_units) relative to row_begin (stream_units = slab_rows here)
 };
 
 // Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch

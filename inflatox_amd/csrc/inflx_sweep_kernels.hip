@@ -226,44 +226,56 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 
   double A[kNP];
   load_params(a.params, p, A);
+  // Stage values come from the tables inflx_stage_tables wrote for this launch (same stage code, evaluated once per
+  // parameter row / grid row / grid column instead of once per workgroup: the U -> R chain is a serial latency of
+  // thousands of dependent instructions on one lane, resp. 32 lanes, that every workgroup used to pay at its start --
+  // 6 % of the D5 sweep and 8 % of the angular one, measured by skipping it).
+  const uint64_t slab_rows = a.stream_units;  // grid rows covered by this launch's tables, first one = stream_row0
+  const double* __restrict__ utab = a.row_table + (uint64_t)p * kNU;
+  const double* __restrict__ rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNR;
+  const double* __restrict__ ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNR) + (uint64_t)p * kNC * a.N1;
+  const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
+  const uint64_t j = col0 + tid;
+  const double x1 = inflx_coord(j, a.dx1, a.x1a);
+  // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
+  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * kTileRows;
+  const uint64_t left = a.row_count - row0;
+  const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
+#ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE  // (A/B experiment only: the round-1 prologue, every workgroup evaluates its own stage values)
 #if INFLX_U_IN_LDS
-  // wave-uniform values: computed once per workgroup, every later use is an LDS broadcast read, so
-  // they cost no long-lived VGPRs (a uniform f64 cannot live in SGPRs: there is no scalar FP unit)
   __shared__ double U[kNU];
-#ifdef INFLX_EXPERIMENT_NO_PROLOGUE  // (timing experiment only: results are wrong)
-  if (tid < kNU) U[tid] = A[tid % kNP] + tid;
-#else
   if (tid == 0) inflx_stage_uniform(A, U);
-#endif
   __syncthreads();
 #else
   double U[kNU];
   inflx_stage_uniform(A, U);
 #endif
-
-  const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
-  const uint64_t j = col0 + tid;
-  const double x1 = inflx_coord(j, a.dx1, a.x1a);
   double C[kNC];
-#ifdef INFLX_EXPERIMENT_NO_PROLOGUE
-  for (int k = 0; k < kNC; ++k) C[k] = x1 * (k + 1.5);
-#else
   inflx_stage_col(x1, A, U, C);
-#endif
-
-  // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
-  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * kTileRows;
-  const uint64_t left = a.row_count - row0;
-  const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
-  if ((int)tid < nrows) {
-    const double x0 = inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a);
-#ifdef INFLX_EXPERIMENT_NO_PROLOGUE
-    for (int k = 0; k < kNR; ++k) Rs[tid][k] = x0 * (k + 0.5) + 1.0;
+  if ((int)tid < nrows) inflx_stage_row(inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a), A, U, Rs[tid]);
+  __syncthreads();
+  (void)utab, (void)rtab, (void)ctab;
 #else
-    inflx_stage_row(x0, A, U, Rs[tid]);
+#if INFLX_U_IN_LDS
+  // wave-uniform values live in LDS: every use is a broadcast read and costs no long-lived VGPRs
+  // (a uniform f64 cannot be an operand from SGPRs more than once per instruction, and there are up to hundreds)
+  __shared__ double U[kNU];
+  for (unsigned k = tid; k < (unsigned)kNU; k += kThreads) U[k] = utab[k];
+#else
+  double U[kNU];
+#pragma unroll
+  for (int k = 0; k < kNU; ++k) U[k] = utab[k];  // uniform address: scalar loads
 #endif
+  double C[kNC];
+#pragma unroll
+  for (int k = 0; k < kNC; ++k) C[k] = j < a.N1 ? ctab[(uint64_t)k * a.N1 + j] : 0.0;
+  {
+    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * kTileRows * kNR;
+    double* dst = &Rs[0][0];
+    for (unsigned i = tid; i < (unsigned)(nrows * kNR); i += kThreads) dst[i] = src[i];
   }
   __syncthreads();
+#endif
 
   const bool in_range = j < a.N1;
   const uint64_t wave_col0 = col0 + (uint64_t)wave * kWave;
@@ -618,6 +630,54 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   apply_op<OP>(mv, o, a.accuracy);
 #pragma unroll
   for (int k = 0; k < K; ++k) store_scalar<OP>(a.out, ((uint64_t)p * a.n + idx) * K + k, o[k]);
+}
+
+// ================================================================================================
+// stage tables of the tile kernels: U per parameter row, R per grid row, C per grid column
+// ================================================================================================
+// grid: x = 256-thread blocks over max(slab rows, N1), y = parameter row.  Table layout (doubles) behind a.row_table:
+//   U[P][kNU]  |  R[P][slab_rows][kNR]  |  C[P][kNC][N1]
+// (R row-major so that a tile's 32 rows are one contiguous block, C value-major so that the threads of a tile read
+// every value coalesced).  The slab is rows [stream_row0, stream_row0 + stream_units) relative to row_begin.
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const InflxSweepArgs a) {
+  const unsigned tid = threadIdx.x;
+  const unsigned p = blockIdx.y;
+  const uint64_t idx = (uint64_t)blockIdx.x * kThreads + tid;
+  const uint64_t slab_rows = a.stream_units;
+  double* utab = a.row_table + (uint64_t)p * kNU;
+  double* rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNR;
+  double* ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNR) + (uint64_t)p * kNC * a.N1;
+  double A[kNP];
+  load_params(a.params, p, A);
+#if INFLX_U_IN_LDS
+  __shared__ double U[kNU];
+  if (tid == 0) inflx_stage_uniform(A, U);
+  __syncthreads();
+  if (blockIdx.x == 0)
+    for (unsigned k = tid; k < (unsigned)kNU; k += kThreads) utab[k] = U[k];
+#else
+  double U[kNU];
+#pragma unroll
+  for (int k = 0; k < kNU; ++k) U[k] = 0.0;
+  inflx_stage_uniform(A, U);
+  if (blockIdx.x == 0 && tid == 0) {
+#pragma unroll
+    for (int k = 0; k < kNU; ++k) utab[k] = U[k];
+  }
+#endif
+  if (idx < slab_rows) {
+    const double x0 = inflx_coord(a.row_begin + a.stream_row0 + idx, a.dx0, a.x0a);
+    inflx_stage_row(x0, A, U, rtab + idx * kNR);
+  }
+  if (idx < a.N1) {
+    const double x1 = inflx_coord(idx, a.dx1, a.x1a);
+    double C[kNC];
+#pragma unroll
+    for (int k = 0; k < kNC; ++k) C[k] = 0.0;
+    inflx_stage_col(x1, A, U, C);
+#pragma unroll
+    for (int k = 0; k < kNC; ++k) ctab[(uint64_t)k * a.N1 + idx] = C[k];
+  }
 }
 
 // ---- entry points (looked up by name with hipModuleGetFunction) --------------------------------
