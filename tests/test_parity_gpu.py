@@ -750,6 +750,16 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
             assert np.array_equal(a, b, equal_nan=True), (name, op, n0, n1)
     s0, s1 = lib.sweep_stats(spec.args, ss, 300, 520), lib_h.sweep_stats(spec.args, ss, 300, 520)
     assert all(np.array_equal(s0[k], s1[k]) for k in ("min", "max", "count"))
+    # Parameters that push the quick stage out of its validity range -- a parameter that is exactly zero (whole
+    # families of zero numerators), 1e-300 and 1e+300 (factors outside [2^-E, 2^E]: the per-stage range flags trip for
+    # the whole sweep, or quotients under- and overflow), a NaN parameter -- must still give the IEEE program's values.
+    for k in range(len(spec.args)):
+        for value in (0.0, 1e-300, 1e300, -spec.args[k], np.nan):
+            args = np.array(spec.args, dtype=np.float64)
+            args[k] = value
+            a = lib.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 70, 130)
+            b = lib_h.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 70, 130)
+            assert np.array_equal(a, b, equal_nan=True), (name, k, value)
 
 
 def test_open_close_cycles_do_not_leak_and_models_coexist(gpu_lib):
