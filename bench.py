@@ -124,6 +124,9 @@ def self_launch(opt) -> int:
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={opt.gpus}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]  # fmt: skip
+    if os.environ.get("INFLX_BENCH_DRY_LAUNCH") == "1":  # tests: show the launch instead of performing it
+        print(json.dumps({"launch": cmd, "HSA_ENABLE_IPC_MODE_LEGACY": env["HSA_ENABLE_IPC_MODE_LEGACY"]}))
+        return 0
     return subprocess.run(cmd, env=env).returncode
 
 

@@ -368,13 +368,189 @@ RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P
   return r;
 }
 
+// ---- the four ways a sweep is enqueued; `a` arrives with the grid geometry filled in (launch_grid) -------------------
+
+// Row-broadcast path: per-row values into the row table on the side stream, then the broadcast store stream on `s`
+// (one 16-byte store per thread, 4 KiB per workgroup).  `what`: 0 = both, 1 = only the evaluation, 2 = only the
+// store stream (used to time the dominant kernel on its own).
+int launch_row_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, int layout, hipStream_t s, int what, double* d_stats) {
+  void* params[] = {&a};
+  const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
+  const RowStreamPlan plan = row_stream_plan(m, op, layout, P, N1, row_count);
+  const size_t cpr = plan.cpr, replicas = plan.replicas, batch = plan.batch;
+  if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
+  const size_t K = kOpWidth[op];
+  // the timing-only mode re-runs store streams from the table of the sweep before it, and only the last
+  // batch's table is still there
+  if (what == 2 && batch < P)
+    return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
+  for (size_t p0 = 0; p0 < P; p0 += batch) {
+    const size_t pb = std::min(batch, P - p0);
+    // `what` == 2 (timing only) re-runs the store streams from whatever the tables hold
+    const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
+    const bool store = d_out != nullptr;
+    int rc = store ? ensure_row_table(m, b, pb * row_count * replicas * 8) : INFLX_OK;
+    if (rc) return rc;
+    a.params = d_params + p0 * m->n_par;
+    a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;  // same offset for [P][rows][N1][K] and [P][K][rows][N1]
+    a.P = (uint32_t)pb;
+    a.row_table = store ? m->d_row_table[b] : nullptr;
+    a.table_replicas = (uint32_t)replicas;
+    a.stream_planes = (uint32_t)K;
+    if (what != 2) {
+      // per-row evaluation on the side stream, as soon as the previous reader of this table is done
+      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+      HIP_TRY(hipModuleLaunchKernel(d_stats ? m->rowvals_stats : m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0,
+                                    m->side, params, nullptr));
+      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+      m->table_turn++;
+    }
+    if (what != 1 && store) {
+      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+      // grid.y is limited to 65535, longer slabs take several launches
+      for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
+        a.stream_row0 = (uint32_t)r0;
+        const size_t nr = std::min<size_t>(65535, row_count - r0);
+        HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
+                                      (unsigned)(aos6 ? pb : pb * K), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+      }
+      HIP_TRY(hipEventRecord(m->table_free[b], s));
+      m->table_used[b] = true;
+    }
+  }
+  return INFLX_OK;
+}
+
+// Column-broadcast path: the image of one output row per parameter row (and plane) into the table on the side stream,
+// then the copy stream on `s`.
+int launch_col_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, int layout, hipStream_t s, int what, double* d_stats) {
+  void* params[] = {&a};
+  const size_t K = kOpWidth[op];
+  const bool planes = layout == INFLX_SOA || K == 1;
+  const size_t images_per_p = planes ? K : 1;
+  const size_t units = (planes ? N1 : K * N1) / 2;  // 16-byte units per output row
+  const size_t cpr = (units + m->info.tile_cols - 1) / m->info.tile_cols;
+  if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
+  const size_t image_doubles = K * N1;  // per parameter row
+  size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(image_doubles * 8, 1)));
+  batch = std::min<size_t>(batch, 65535 / images_per_p);
+  if (what == 2 && batch < P)
+    return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
+  const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
+  for (size_t p0 = 0; p0 < P; p0 += batch) {
+    const size_t pb = std::min(batch, P - p0);
+    const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
+    const bool store = d_out != nullptr;
+    int rc = store ? ensure_row_table(m, b, pb * image_doubles) : INFLX_OK;
+    if (rc) return rc;
+    a.params = d_params + p0 * m->n_par;
+    a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;
+    a.P = (uint32_t)pb;
+    a.row_table = store ? m->d_row_table[b] : nullptr;
+    a.stream_units = units;
+    if (what != 2) {
+      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+      HIP_TRY(hipModuleLaunchKernel(d_stats ? m->colvals_stats : m->colvals[op], (unsigned)gx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params,
+                                    nullptr));
+      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+      m->table_turn++;
+    }
+    if (what != 1 && store) {
+      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+      for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
+        a.stream_row0 = (uint32_t)r0;
+        const size_t nr = std::min<size_t>(65535, row_count - r0);
+        HIP_TRY(hipModuleLaunchKernel(m->colstream, (unsigned)cpr, (unsigned)nr, (unsigned)(pb * images_per_p), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+      }
+      HIP_TRY(hipEventRecord(m->table_free[b], s));
+      m->table_used[b] = true;
+    }
+  }
+  return INFLX_OK;
+}
+
+// Fallback of row-only models for result shapes the store streams do not cover: per-row evaluation inside the kernel.
+int launch_rows_fallback(inflx_model* m, int op, InflxSweepArgs a, size_t P, size_t N1, size_t row_count, hipStream_t s) {
+  void* params[] = {&a};
+  const size_t rpb = m->info.rows_per_block;
+  const size_t groups = (row_count + rpb - 1) / rpb;
+  // few rows: split each row into column chunks until the grid can fill 256 CUs x 8 workgroups
+  size_t chunks = 1;
+  const size_t want = 4096;
+  if (groups * P < want) {
+    const size_t units = N1 / 64;
+    chunks = std::min<size_t>(std::max<size_t>(units, 1), (want + groups * P - 1) / (groups * P));
+  }
+  if (groups * chunks > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid too large for one launch");
+  a.col_chunks = (uint32_t)chunks;
+  HIP_TRY(hipModuleLaunchKernel(m->rows[op], (unsigned)(groups * chunks), (unsigned)P, 1, m->info.tile_cols, 1, 1, 0, s, params,
+                                nullptr));
+  return INFLX_OK;
+}
+
+// Tile path (some value depends on x[1]).  Stage tables U[P][nu] | R[P][slab][nr] | C[P][nc][N1] (doubles) are written
+// by inflx_stage_tables on the side stream into one of two buffers and read by the tile kernel on `s` behind an event,
+// so that in a sequence of launches the tables of launch n+1 are evaluated while the tile kernel of launch n runs.
+// grid.y is limited to 65535 tiles: a taller slab takes several launches, each with tables of its own; parameter rows
+// are batched so that one set of tables stays below 1 GiB.
+int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
+                 double* d_stats) {
+  void* params[] = {&a};
+  const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
+  if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch (%zu column tiles)", gx);
+  if (row_count > 0xffffffffULL) return fail(INFLX_ERR_SHAPE, "at most 2^32 grid rows per call (got %zu)", row_count);
+  hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
+  const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nr = std::max<size_t>(m->info.n_row, 1), nc = std::max<size_t>(m->info.n_col, 1);
+  const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
+  const size_t slab_max = std::min(rows_per_launch, row_count);
+  const size_t per_p = nu + slab_max * nr + nc * N1;  // doubles per parameter row
+  const size_t pbatch = std::max<size_t>(1, std::min<size_t>(P, (size_t(1) << 27) / std::max<size_t>(per_p, 1)));
+  for (size_t p0 = 0; p0 < P; p0 += pbatch) {
+    const size_t pb = std::min(pbatch, P - p0);
+    a.params = d_params + p0 * m->n_par;
+    a.out = d_out ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_out) + p0 * row_count * N1 * kOpBytes[op]) : nullptr;
+    a.P = (uint32_t)pb;
+    for (size_t r0 = 0; r0 < row_count; r0 += rows_per_launch) {
+      const size_t slab = std::min(rows_per_launch, row_count - r0);
+      const size_t need = pb * (nu + slab * nr + nc * N1);
+      const int b = (int)(m->stage_turn & 1);
+      if (need > m->d_stage_tab_cap[b]) {
+        // nothing may still be reading the old tables
+        if (m->stage_used[b]) HIP_TRY(hipEventSynchronize(m->stage_free[b]));
+        if (m->d_stage_tab[b]) HIP_TRY(hipFree(m->d_stage_tab[b]));
+        m->d_stage_tab[b] = nullptr;
+        m->d_stage_tab_cap[b] = 0;
+        HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stage_tab[b]), need * sizeof(double)));
+        m->d_stage_tab_cap[b] = need;
+      }
+      a.row_table = m->d_stage_tab[b];
+      a.stream_row0 = (uint32_t)r0;
+      a.stream_units = slab;
+      // tables on the side stream, as soon as the tile kernel that read this buffer two launches ago is done ...
+      if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->stage_free[b], 0));
+      const size_t tx = (std::max(slab, N1) + m->info.tile_cols - 1) / m->info.tile_cols;
+      HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params, nullptr));
+      HIP_TRY(hipEventRecord(m->stage_ready[b], m->side));
+      m->stage_turn++;
+      // ... and the tile kernel on the caller's stream behind them
+      HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
+      const size_t gy = (slab + m->info.tile_rows - 1) / m->info.tile_rows;
+      HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+      HIP_TRY(hipEventRecord(m->stage_free[b], s));
+      m->stage_used[b] = true;
+    }
+  }
+  return INFLX_OK;
+}
+
 // Enqueue one sweep on `s`; `d_params` points at P parameter rows in device memory.
-// `what`: 0 = the whole sweep; for the two-launch row-broadcast path 1 = only the per-row evaluation,
+// `what`: 0 = the whole sweep; for the two-launch broadcast paths 1 = only the evaluation,
 // 2 = only the store stream (used to time the dominant kernel on its own).
 int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double* d_out, const double* ss, size_t N0, size_t N1,
                 size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0, double accuracy = 0.0,
                 double* d_stats = nullptr) {
   if (row_count == 0 || N1 == 0) return INFLX_OK;
+  if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
   InflxSweepArgs a;
   memset(&a, 0, sizeof a);
   a.out = d_out;
@@ -392,165 +568,12 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   a.col_chunks = 1;
   a.accuracy = accuracy;
   a.stats = d_stats;  // non-NULL: complete_analysis with the running summary (d_out may then be NULL)
-  void* params[] = {&a};
+  if (takes_row_stream(m, op, layout, P, N1)) return launch_row_stream(m, op, a, d_params, P, d_out, N1, row_count, layout, s, what, d_stats);
+  if (takes_col_stream(m, op, layout, P, N1)) return launch_col_stream(m, op, a, d_params, P, d_out, N1, row_count, layout, s, what, d_stats);
   // the flag sweep reads the basis vector, whose axis dependence the out_mask does not describe
   const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
-  if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
-  const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
-  if (takes_row_stream(m, op, layout, P, N1)) {
-    // two launches: per-row values into the row table, then the broadcast store stream (one 16-byte
-    // store per thread, 4 KiB per workgroup); `what` selects both (0), or one of them for timing
-    const RowStreamPlan plan = row_stream_plan(m, op, layout, P, N1, row_count);
-    const size_t cpr = plan.cpr, replicas = plan.replicas, batch = plan.batch;
-    if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
-    const size_t K = kOpWidth[op];
-    // the timing-only mode re-runs store streams from the table of the sweep before it, and only the last
-    // batch's table is still there
-    if (what == 2 && batch < P)
-      return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
-    for (size_t p0 = 0; p0 < P; p0 += batch) {
-      const size_t pb = std::min(batch, P - p0);
-      // `what` == 2 (timing only) re-runs the store streams from whatever the tables hold
-      const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
-      const bool store = d_out != nullptr;
-      int rc = store ? ensure_row_table(m, b, pb * row_count * replicas * 8) : INFLX_OK;
-      if (rc) return rc;
-      a.params = d_params + p0 * m->n_par;
-      a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;  // same offset for [P][rows][N1][K] and [P][K][rows][N1]
-      a.P = (uint32_t)pb;
-      a.row_table = store ? m->d_row_table[b] : nullptr;
-      a.table_replicas = (uint32_t)replicas;
-      a.stream_planes = (uint32_t)K;
-      if (what != 2) {
-        // per-row evaluation on the side stream, as soon as the previous reader of this table is done
-        if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
-        HIP_TRY(hipModuleLaunchKernel(d_stats ? m->rowvals_stats : m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0,
-                                      m->side, params, nullptr));
-        HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
-        m->table_turn++;
-      }
-      if (what != 1 && store) {
-        HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
-        // grid.y is limited to 65535, longer slabs take several launches
-        for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
-          a.stream_row0 = (uint32_t)r0;
-          const size_t nr = std::min<size_t>(65535, row_count - r0);
-          HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
-                                        (unsigned)(aos6 ? pb : pb * K), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
-        }
-        HIP_TRY(hipEventRecord(m->table_free[b], s));
-        m->table_used[b] = true;
-      }
-    }
-  } else if (takes_col_stream(m, op, layout, P, N1)) {
-    // two launches: the image of one output row per parameter row (and plane) into the table, then the copy stream
-    const size_t K = kOpWidth[op];
-    const bool planes = layout == INFLX_SOA || K == 1;
-    const size_t images_per_p = planes ? K : 1;
-    const size_t units = (planes ? N1 : K * N1) / 2;  // 16-byte units per output row
-    const size_t cpr = (units + m->info.tile_cols - 1) / m->info.tile_cols;
-    if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
-    const size_t image_doubles = K * N1;  // per parameter row
-    size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(image_doubles * 8, 1)));
-    batch = std::min<size_t>(batch, 65535 / images_per_p);
-    if (what == 2 && batch < P)
-      return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
-    const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
-    for (size_t p0 = 0; p0 < P; p0 += batch) {
-      const size_t pb = std::min(batch, P - p0);
-      const int b = what == 2 ? (int)((m->table_turn + 1) & 1) : (int)(m->table_turn & 1);
-      const bool store = d_out != nullptr;
-      int rc = store ? ensure_row_table(m, b, pb * image_doubles) : INFLX_OK;
-      if (rc) return rc;
-      a.params = d_params + p0 * m->n_par;
-      a.out = store ? d_out + p0 * row_count * N1 * K : nullptr;
-      a.P = (uint32_t)pb;
-      a.row_table = store ? m->d_row_table[b] : nullptr;
-      a.stream_units = units;
-      if (what != 2) {
-        if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
-        HIP_TRY(hipModuleLaunchKernel(d_stats ? m->colvals_stats : m->colvals[op], (unsigned)gx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params,
-                                      nullptr));
-        HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
-        m->table_turn++;
-      }
-      if (what != 1 && store) {
-        HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
-        for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
-          a.stream_row0 = (uint32_t)r0;
-          const size_t nr = std::min<size_t>(65535, row_count - r0);
-          HIP_TRY(hipModuleLaunchKernel(m->colstream, (unsigned)cpr, (unsigned)nr, (unsigned)(pb * images_per_p), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
-        }
-        HIP_TRY(hipEventRecord(m->table_free[b], s));
-        m->table_used[b] = true;
-      }
-    }
-  } else if (row_uniform) {
-    const size_t rpb = m->info.rows_per_block;
-    const size_t groups = (row_count + rpb - 1) / rpb;
-    // few rows: split each row into column chunks until the grid can fill 256 CUs x 8 workgroups
-    size_t chunks = 1;
-    const size_t want = 4096;
-    if (groups * P < want) {
-      const size_t units = N1 / 64;
-      chunks = std::min<size_t>(std::max<size_t>(units, 1), (want + groups * P - 1) / (groups * P));
-    }
-    if (groups * chunks > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid too large for one launch");
-    a.col_chunks = (uint32_t)chunks;
-    HIP_TRY(hipModuleLaunchKernel(m->rows[op], (unsigned)(groups * chunks), (unsigned)P, 1, m->info.tile_cols, 1, 1, 0, s, params,
-                                  nullptr));
-  } else {
-    const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
-    if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch (%zu column tiles)", gx);
-    if (row_count > 0xffffffffULL) return fail(INFLX_ERR_SHAPE, "at most 2^32 grid rows per call (got %zu)", row_count);
-    hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
-    // Stage tables: U[P][nu] | R[P][slab][nr] | C[P][nc][N1] doubles, written by inflx_stage_tables on the same stream
-    // right before the tile kernel that reads them.  grid.y is limited to 65535 tiles, so a taller slab takes several
-    // launches, each with tables of its own; parameter rows are batched so that one set of tables stays below 1 GiB.
-    const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nr = std::max<size_t>(m->info.n_row, 1), nc = std::max<size_t>(m->info.n_col, 1);
-    const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
-    const size_t slab_max = std::min(rows_per_launch, row_count);
-    const size_t per_p = nu + slab_max * nr + nc * N1;  // doubles per parameter row
-    const size_t pbatch = std::max<size_t>(1, std::min<size_t>(P, (size_t(1) << 27) / std::max<size_t>(per_p, 1)));
-    const size_t K = kOpWidth[op];
-    for (size_t p0 = 0; p0 < P; p0 += pbatch) {
-      const size_t pb = std::min(pbatch, P - p0);
-      a.params = d_params + p0 * m->n_par;
-      a.out = d_out ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_out) + p0 * row_count * N1 * kOpBytes[op]) : nullptr;
-      a.P = (uint32_t)pb;
-      (void)K;
-      for (size_t r0 = 0; r0 < row_count; r0 += rows_per_launch) {
-        const size_t slab = std::min(rows_per_launch, row_count - r0);
-        const size_t need = pb * (nu + slab * nr + nc * N1);
-        const int b = (int)(m->stage_turn & 1);
-        if (need > m->d_stage_tab_cap[b]) {
-          // nothing may still be reading the old tables
-          if (m->stage_used[b]) HIP_TRY(hipEventSynchronize(m->stage_free[b]));
-          if (m->d_stage_tab[b]) HIP_TRY(hipFree(m->d_stage_tab[b]));
-          m->d_stage_tab[b] = nullptr;
-          m->d_stage_tab_cap[b] = 0;
-          HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stage_tab[b]), need * sizeof(double)));
-          m->d_stage_tab_cap[b] = need;
-        }
-        a.row_table = m->d_stage_tab[b];
-        a.stream_row0 = (uint32_t)r0;
-        a.stream_units = slab;
-        // tables on the side stream, as soon as the tile kernel that read this buffer two launches ago is done ...
-        if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->stage_free[b], 0));
-        const size_t tx = (std::max(slab, N1) + m->info.tile_cols - 1) / m->info.tile_cols;
-        HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params, nullptr));
-        HIP_TRY(hipEventRecord(m->stage_ready[b], m->side));
-        m->stage_turn++;
-        // ... and the tile kernel on the caller's stream behind them
-        HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
-        const size_t gy = (slab + m->info.tile_rows - 1) / m->info.tile_rows;
-        HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
-        HIP_TRY(hipEventRecord(m->stage_free[b], s));
-        m->stage_used[b] = true;
-      }
-    }
-  }
-  return INFLX_OK;
+  if (row_uniform) return launch_rows_fallback(m, op, a, P, N1, row_count, s);
+  return launch_tiles(m, op, a, d_params, P, d_out, N1, row_count, s, d_stats);
 }
 
 int ensure_chunk(inflx_model* m, int which, size_t bytes) {
