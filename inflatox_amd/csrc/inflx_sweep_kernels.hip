@@ -466,7 +466,10 @@ __device__ __forceinline__ void sweep_rowvals(const InflxSweepArgs& a) {
 __device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
   // grid: x = 4 KiB piece within the grid row, y = grid row (relative to stream_row0), z = parameter row;
   // no index arithmetic beyond multiply-add -- with one store per thread even a 64-bit division per
-  // workgroup (flat grid -> (row, piece)) costs 30 % of the bandwidth
+  // workgroup (flat grid -> (row, piece)) costs 30 % of the bandwidth.
+  // (An XCD-aware remap -- every XCD takes one whole grid row of each group of 8, so that its L2 write-combines 384 KiB
+  // runs instead of 4 KiB pieces 32 KiB apart -- gains 3 % in the pure-store microbenchmark, scripts/micro/store_bw.hip
+  // variant X, but LOSES 1.7 % here, A/B in one session: 0.472 against 0.464 ms per sweep.  The identity map stays.)
   const uint64_t units_row = 3 * a.N1;
   const unsigned k = blockIdx.x;
   const uint64_t row = (uint64_t)a.stream_row0 + blockIdx.y;

@@ -14,7 +14,7 @@ import workloads  # noqa: E402
 from workloads import example_models  # noqa: E402
 from inflatox_amd.compiler import Compiler  # noqa: E402
 
-n = 4096
+n = int(os.environ.get("INFLX_EXPERIMENT_N", "4096"))
 stream = torch.cuda.current_stream().cuda_stream
 out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
 cases = sys.argv[1:] or ["d5", "d5:hoist", "egno", "egno:hoist"]

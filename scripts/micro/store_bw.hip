@@ -73,6 +73,17 @@ template <bool NT, int THREADS> __global__ __launch_bounds__(THREADS) void one_s
   if (u < total_units) st<NT>(out + 2 * u, v);
 }
 
+// X: F with an XCD-aware remap of workgroup -> 4-KiB piece: workgroups are dispatched round-robin over the 8 XCDs
+// (blockIdx % 8), so with run = G consecutive pieces per XCD each XCD's L2 write-combines contiguous runs of G * 4 KiB;
+// G = nblocks/8 gives every XCD one contiguous eighth of the buffer, G = 1 is F itself
+template <bool NT> __global__ __launch_bounds__(256) void one_store_xcd(double* out, uint64_t total_units, uint64_t run) {
+  const uint64_t b = blockIdx.x, xcd = b & 7, k = b >> 3;          // k-th workgroup of this XCD
+  const uint64_t piece = ((k / run) * 8 + xcd) * run + (k % run);  // super-chunk k/run, XCD's run inside it, position in the run
+  const uint64_t u = piece * 256 + threadIdx.x;
+  d2 v = {1.0 + threadIdx.x, 2.0};
+  if (u < total_units) st<NT>(out + 2 * u, v);
+}
+
 // G: the product's inflx_sweep_rowstream6 logic (3-D grid, row table, phase select), parameterised
 struct GArgs { double* out; const double* table; uint64_t N1; uint64_t row_count; uint32_t stream_row0; };
 template <int MODE> __global__ __launch_bounds__(256) void rowstream_like(const GArgs a) {
@@ -202,6 +213,13 @@ int main() {
   }
   timeit("E 2x16B adjacent/thread nt 256thr", [&] { two_adjacent<true, 256><<<(unsigned)((total / 2 + 255) / 256), 256>>>(d, total); });
   timeit("E 2x16B adjacent/thread plain 256thr", [&] { two_adjacent<false, 256><<<(unsigned)((total / 2 + 255) / 256), 256>>>(d, total); });
+  for (uint64_t run : {1ull, 2ull, 4ull, 16ull, 64ull, 256ull, 4096ull, (unsigned long long)((total + 255) / 256 / 8)}) {
+    char label[96];
+    snprintf(label, sizeof label, "X 1 store/thread nt, XCD runs of %llu x 4 KiB", (unsigned long long)run);
+    const uint64_t nb = (total + 255) / 256;
+    const uint64_t nb8 = (nb + 8 * run - 1) / (8 * run) * (8 * run);  // whole super-chunks (extra workgroups store nothing)
+    timeit(label, [&] { one_store_xcd<true><<<(unsigned)nb8, 256>>>(d, total, run); });
+  }
   timeit("F 1 store/thread nt 64thr", [&] { one_store<true, 64><<<(unsigned)((total + 63) / 64), 64>>>(d, total); });
   timeit("F 1 store/thread nt 128thr", [&] { one_store<true, 128><<<(unsigned)((total + 127) / 128), 128>>>(d, total); });
   timeit("F 1 store/thread nt 256thr", [&] { one_store<true, 256><<<(unsigned)((total + 255) / 256), 256>>>(d, total); });
