@@ -25,6 +25,7 @@ so a user's ``args`` array means the same thing here as there.
 from __future__ import annotations
 
 import hashlib
+import re
 import os
 import shutil
 import subprocess
@@ -209,6 +210,17 @@ class CompilationArtifact:
         print("[Symbol Dictionary]")
         for old, new in self.symbol_dictionary.items():
             print(f"{old} -> {new}")
+
+
+_COMMENT = re.compile(r'"(?:\\.|[^"\\])*"|//[^\n]*|/\*.*?\*/', re.S)
+
+
+def _code_only(source: str) -> str:
+    """C/C++ source without comments and blank lines (string literals kept): what the content tag of a code object
+    hashes, so that editing a comment in the kernel sources neither rebuilds every model nor orphans the profiles
+    that are stamped with the tag."""
+    text = _COMMENT.sub(lambda m: m.group(0) if m.group(0).startswith('"') else " ", source)
+    return "\n".join(ln.rstrip() for ln in text.splitlines() if ln.strip())
 
 
 def _cache_dir() -> str:
@@ -424,8 +436,8 @@ class Compiler:
         h = hashlib.sha256()
         h.update(header_text.encode())
         for d in deps:
-            with open(d, "rb") as fh:
-                h.update(fh.read())
+            with open(d, "r", encoding="utf-8") as fh:
+                h.update(_code_only(fh.read()).encode())
         opts = list(self.hipcc_opts)
         if self.gsl:
             opts.append("-DINFLX_USE_GSL=1")

@@ -12,9 +12,9 @@
 //  * tile kernels (inflx_sweep_tile_*): a 256-thread workgroup owns a tile of TILE_ROWS grid rows
 //    x 256 grid columns for one parameter row.  Lane <-> column j (the fast axis of the output),
 //    so a wavefront covers 64 consecutive points of one grid row = 64*K*8 contiguous bytes.
-//    Column-only sub-expressions are evaluated once per thread and live in registers; row-only
-//    sub-expressions are evaluated once per tile row by one lane each and are staged in LDS,
-//    from where all lanes read them as a broadcast; parameters sit in registers/SGPRs.
+//    Parameter-only, row-only and column-only sub-expressions are evaluated ONCE PER LAUNCH by inflx_stage_tables
+//    (one lane per parameter row / grid row / grid column) into tables; a workgroup loads its column's values into
+//    registers and its 32 rows' values into LDS, from where all lanes read them as a broadcast.
 //    For the 6-value AoS result a wavefront transposes its 64x6 block through a private 3 KiB LDS
 //    buffer so that every global store instruction writes 1 KiB of contiguous memory (16 B/lane).
 //
@@ -22,7 +22,7 @@
 //    the per-point operation is then a function of the grid row only.  inflx_sweep_rowvals_* evaluates
 //    it once per row into a small table, inflx_sweep_rowstream6 / _planes broadcast it along the row:
 //    a pure store stream, ONE 16-byte store per thread and 4 KiB per workgroup, which is what the
-//    HBM roofline prices (7.0-7.1 TB/s measured).  inflx_sweep_rows_* is the fallback for result
+//    HBM roofline prices (6.9-7.2 TB/s measured).  inflx_sweep_rows_* is the fallback for result
 //    shapes the stream kernels do not cover (odd N1 planes, the 5-value AoS diagnostic).
 //
 //  * column-broadcast path, used when no model value depends on x[0]: inflx_sweep_colvals_* evaluates the image of

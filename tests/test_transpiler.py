@@ -279,3 +279,15 @@ def test_abs_quotient_sign_identity_used_by_the_epilogue():
         got = np.copysign(np.abs(a / b), b)
     same = (want.view(np.uint64) == got.view(np.uint64)) | (np.isnan(want) & np.isnan(got))
     assert same.all(), (a[~same][:5], b[~same][:5])
+
+
+def test_content_tag_ignores_comments_in_the_kernel_sources():
+    """The cache tag of a code object (which profiles are stamped with) hashes the kernel sources without comments and
+    blank lines: string literals survive, code changes change it."""
+    from inflatox_amd.compiler import _code_only
+
+    a = 'int f() { return 1; }  // one\n/* block\n comment */\nconst char* s = "a//b /* c */";\n\n'
+    b = '// header\nint f() { return 1; }\nconst char* s = "a//b /* c */";  /* x */\n'
+    assert _code_only(a) == _code_only(b)
+    assert '"a//b /* c */"' in _code_only(a)
+    assert _code_only(a) != _code_only(a.replace("return 1", "return 2"))
