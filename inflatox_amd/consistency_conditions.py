@@ -13,6 +13,7 @@ import numpy as np
 
 from . import _native
 from ._native import InflatoxDevLib, open_inflx_dylib
+from ._result_pool import result_array
 from .compiler import CompilationArtifact
 
 __all__ = ["InflationCondition", "GeneralisedAL"]
@@ -103,7 +104,9 @@ class GeneralisedAL(InflationCondition):
         x0 = x0_start + i·(x0_stop-x0_start)/N_x0, x1 likewise (end point excluded).
         Reference: consistency_conditions.py:226-308; like there, the six arrays are strided views
         of one (N_x0, N_x1, 6) array."""
-        out = np.zeros((N_x0, N_x1, 6), dtype=float)
+        # the reference's np.zeros((N_x0, N_x1, 6)); recycled page-resident memory when a previous result of this size
+        # has been dropped (_result_pool.py) -- the sweep writes every element
+        out = result_array((N_x0, N_x1, 6))
         start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
         threads = threads if threads is not None else 0
         self.dylib.complete_analysis(args, out, start_stop, progress, threads)
@@ -136,7 +139,7 @@ class GeneralisedAL(InflationCondition):
 
     # ---- single-quantity sweeps (reference :310-475) ---------------------------------------------
     def _single(self, fn, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads):
-        out = np.zeros((N_x0, N_x1), dtype=float)
+        out = result_array((N_x0, N_x1))
         start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
         threads = threads if threads is not None else 0
         fn(args, out, start_stop, progress, threads)
@@ -154,7 +157,7 @@ class GeneralisedAL(InflationCondition):
     def flag_quantum_dif(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=10_000, N_x1=10_000, progress=True, accuracy=1e-3) -> np.ndarray:
         """Boolean (N_x0, N_x1) array: True where both components of the normalised potential gradient
         are <= ``accuracy`` (reference consistency_conditions.py:477-523, src/anguelova.rs:166-170)."""
-        x = np.zeros((N_x0, N_x1), dtype=bool)
+        x = result_array((N_x0, N_x1), dtype=bool)
         self.dylib.flag_quantum_dif(args, x, _start_stop(x0_start, x0_stop, x1_start, x1_stop), progress, accuracy)
         return x
 

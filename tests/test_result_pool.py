@@ -1,0 +1,46 @@
+"""inflatox_amd/_result_pool.py: result arrays are ordinary writeable arrays, a buffer is recycled only after the last
+view of the result that used it is gone, and live results never share memory."""
+
+import gc
+
+import numpy as np
+
+from inflatox_amd import _result_pool as pool
+
+
+def _addr(a):
+    return a.__array_interface__["data"][0]
+
+
+def test_buffers_come_back_only_when_every_view_is_gone():
+    gc.collect()
+    a = pool.result_array((50, 40, 6))
+    assert a.shape == (50, 40, 6) and a.dtype == np.float64 and a.flags.c_contiguous and a.flags.writeable
+    a[...] = 1.5
+    views = (a[:, :, 0], a[:, :, 5])  # what complete_analysis returns: strided views of the (N0, N1, 6) array
+    assert views[0].strides == (40 * 48, 48)
+    addr = _addr(a)
+    held = pool.held_bytes()
+    del a
+    gc.collect()
+    assert pool.held_bytes() == held  # still referenced by the views
+    b = pool.result_array((50, 40, 6))
+    assert _addr(b) != addr and not np.shares_memory(b, views[0])
+    assert float(views[1][3, 4]) == 1.5
+    del views
+    gc.collect()
+    assert pool.held_bytes() == held + 50 * 40 * 48  # the first buffer is back
+    c = pool.result_array((50, 40, 6))
+    assert _addr(c) == addr  # and is reused for the next result of that size
+    d = pool.result_array((40, 50, 6))  # same byte count, another shape: any free buffer of the size will do
+    assert d.shape == (40, 50, 6) and not np.shares_memory(c, d) and not np.shares_memory(b, d)
+
+
+def test_other_dtypes_sizes_and_the_limit():
+    f = pool.result_array((30, 20), dtype=bool)
+    assert f.dtype == np.bool_ and f.shape == (30, 20)
+    f[...] = True
+    assert f.all()
+    assert pool.result_array((0, 7, 6)).shape == (0, 7, 6)
+    big = pool.result_array((pool._LIMIT // 8 // 6 + 1, 1, 6))  # above half of the bound: a plain numpy array
+    assert big.base is None or isinstance(big.base, np.ndarray) and big.base.base is None
