@@ -306,7 +306,9 @@ class InflatoxDevLib:
             shape = (P, row_count, N1, k)
         else:
             shape = (P, k, row_count, N1)
-        out = np.empty(shape)
+        from ._result_pool import result_array
+
+        out = result_array(shape)  # recycled page-resident memory where a dropped result of this size is at hand
         _check(self._lib.inflx_sweep_host(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, layout))
         return out[0] if single else out
 
