@@ -38,8 +38,8 @@ def _give_back(buf, nbytes: int) -> None:
         if len(lst) < _PER_SIZE and _held + nbytes <= _LIMIT:
             lst.append(buf)
             _held += nbytes
-            return
-    buf.close()
+    # not pooled: the mapping is unmapped when this last reference goes (no explicit close(): the dying owner array may
+    # still hold its buffer export at this point)
 
 
 def result_array(shape, dtype=np.float64) -> np.ndarray:

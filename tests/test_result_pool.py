@@ -44,3 +44,13 @@ def test_other_dtypes_sizes_and_the_limit():
     assert pool.result_array((0, 7, 6)).shape == (0, 7, 6)
     big = pool.result_array((pool._LIMIT // 8 // 6 + 1, 1, 6))  # above half of the bound: a plain numpy array
     assert big.base is None or isinstance(big.base, np.ndarray) and big.base.base is None
+
+
+def test_overflowing_the_pool_is_silent(recwarn):
+    """More dropped results than the pool keeps per size: the surplus mappings are simply released."""
+    arrays = [pool.result_array((64, 64, 6)) for _ in range(pool._PER_SIZE + 3)]
+    held = pool.held_bytes()
+    del arrays
+    gc.collect()
+    assert pool.held_bytes() <= held + pool._PER_SIZE * 64 * 64 * 48
+    assert not [w for w in recwarn.list if "Unraisable" in str(w.category)]
