@@ -414,7 +414,10 @@ def main():
             except Exception as exc:  # noqa: BLE001
                 line["end_to_end"] = {"error": str(exc)[:300]}
         if world == 1 and not opt.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(opt.model, spec.args, spec.extent)
+            try:
+                line["cpu_baseline"] = cpu_baseline(opt.model, spec.args, spec.extent)
+            except Exception as exc:  # noqa: BLE001 -- the reported baseline must never cost the benchmark line
+                line["cpu_baseline"] = {"error": str(exc)[:300]}
         print(json.dumps(line), flush=True)
     if distributed:
         dist.destroy_process_group()
