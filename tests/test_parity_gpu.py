@@ -23,10 +23,12 @@ STRICT_GOLDEN = ("hyperbolic", "doc")  # ... and on the golden grids (doc measur
 GRID_TAGS = {"hyperbolic": ("g16", "g64", "ragged"), "doc": ("g16", "g64", "neg"), "angular": ("g16", "g64", "inner"), "egno": ("g16", "g64"), "d5": ("g16", "g64")}
 
 
-def judge(name, args, pts, shape, ref_raw, got, ref, fn, what, golden_grid=False):
+def judge(name, args, pts, shape, ref_raw, got, ref, fn, what, golden_grid=False, neighbourhood=False):
     """Apply the criterion to `got` vs `ref` (fn maps model values to the compared quantity; None = the model values themselves)."""
     env, flaky = tol.reference_error(name, args, pts)
     env, flaky = env.reshape(*shape, 5), flaky.reshape(*shape, 5)
+    if neighbourhood:  # grids only: E maximised over the grid neighbours too (tolerance.neighbourhood_envelope)
+        env = tol.neighbourhood_envelope(env)
     if fn is None:
         worst = tol.check(got, ref, tol.allowance_raw(ref_raw, env, name), flaky, what, model=name)
     else:
@@ -100,6 +102,29 @@ def test_matches_oracle_on_fresh_grid(name, gpu_lib):
         want = om.grid_sweep(OP.COMPLETE, spec.args, ext, n0, n1, threads=4)
         raw = om.grid_sweep(OP.RAW, spec.args, ext, n0, n1, threads=4)
         judge(name, spec.args, oracle.grid_points(ext, n0, n1), (n0, n1), raw, got, want, tol.epilogue, f"{name}/{n0}x{n1}")
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_random_parameter_vectors_match_the_oracle(name, gpu_lib):
+    """Parameter values other than the ones the goldens were made with: six seeded parameter vectors per model (every
+    parameter scaled by a factor in [0.7, 1.4]), complete_analysis and the raw model values on a ragged grid inside the
+    model's extent, judged against the oracle with the measured-error criterion (the allowance is re-measured for every
+    parameter vector)."""
+    spec, art, lib = devlib(name, gpu_lib)
+    om, _ = oracle_model(name)
+    rng = np.random.default_rng(20260 + len(name))
+    x0a, x0b, x1a, x1b = spec.extent
+    ext = (x0a + 0.021 * (x0b - x0a), x0b - 0.013 * (x0b - x0a), x1a + 0.017 * (x1b - x1a), x1b - 0.019 * (x1b - x1a))
+    n0, n1 = 37, 83
+    pts = oracle.grid_points(ext, n0, n1)
+    for trial in range(6):
+        args = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.7, 1.4, size=len(spec.args))
+        want = om.grid_sweep(OP.COMPLETE, args, ext, n0, n1, threads=4)
+        raw = om.grid_sweep(OP.RAW, args, ext, n0, n1, threads=4)
+        got = lib.sweep_host(gpu_lib.OP_COMPLETE, args, ext, n0, n1)
+        judge(name, args, pts, (n0, n1), raw, got, want, tol.epilogue, f"{name}/random parameters {trial}", neighbourhood=True)
+        got_raw = lib.sweep_host(gpu_lib.OP_RAW, args, ext, n0, n1)
+        judge(name, args, pts, (n0, n1), raw, got_raw, raw, None, f"{name}/random parameters {trial}/raw", neighbourhood=True)
 
 
 def test_drop_in_front_end(gpu_lib):

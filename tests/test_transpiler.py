@@ -291,3 +291,27 @@ def test_content_tag_ignores_comments_in_the_kernel_sources():
     assert _code_only(a) == _code_only(b)
     assert '"a//b /* c */"' in _code_only(a)
     assert _code_only(a) != _code_only(a.replace("return 1", "return 2"))
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_staged_header_on_host_matches_oracle_for_random_parameters(name):
+    """The CPU side of tests/test_parity_gpu.py::test_random_parameter_vectors_match_the_oracle: the staged header
+    (value numbering, hoisted reciprocals where they are on, range flags) evaluated on the host for seeded parameter
+    vectors against the oracle."""
+    _, hdr = header_for(name)
+    tw = HostTwin(hdr)
+    om, _ = oracle_model(name)
+    spec = example_models.get(name)
+    rng = np.random.default_rng(20260 + len(name))
+    x0a, x0b, x1a, x1b = spec.extent
+    ext = (x0a + 0.021 * (x0b - x0a), x0b - 0.013 * (x0b - x0a), x1a + 0.017 * (x1b - x1a), x1b - 0.019 * (x1b - x1a))
+    n0, n1 = 23, 41
+    pts = oracle.grid_points(ext, n0, n1)
+    for trial in range(3):
+        args = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.7, 1.4, size=len(spec.args))
+        env, flaky = tol.reference_error(name, args, pts)
+        env, flaky = tol.neighbourhood_envelope(env.reshape(n0, n1, 5)), flaky.reshape(n0, n1, 5)
+        raw = om.grid_sweep(oracle.OP.RAW, args, ext, n0, n1)
+        want = om.grid_sweep(oracle.OP.COMPLETE, args, ext, n0, n1)
+        tol.check(tw.grid(4, args, ext, n0, n1), raw, tol.allowance_raw(raw, env, name), flaky, f"{name}/random {trial}/raw", model=name)
+        tol.check(tw.grid(0, args, ext, n0, n1), want, tol.allowance_derived(raw, env, tol.epilogue, name), flaky.any(axis=-1)[..., None], f"{name}/random {trial}/out", model=name)
