@@ -317,7 +317,8 @@ int ensure_row_table(inflx_model* m, int b, size_t doubles) {
 bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
   if ((m->info.out_mask & 2u) != 0 || op == INFLX_OP_QDIF) return false;
   const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
-  const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0 && P * kOpWidth[op] <= 65535;
+  (void)P;  // the path never depends on the number of parameter rows: they are batched (row_stream_plan)
+  const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0;
   return aos6 || planes;
 }
 
@@ -327,8 +328,9 @@ bool takes_col_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   if ((m->info.out_mask & 3u) != 2u || op == INFLX_OP_QDIF) return false;
   const size_t K = kOpWidth[op];
   const bool planes = layout == INFLX_SOA || K == 1;
-  if (planes) return N1 % 2 == 0 && P * K <= 65535;
-  return (K * N1) % 2 == 0 && P <= 65535;
+  (void)P;  // batched in launch_col_stream
+  if (planes) return N1 % 2 == 0;
+  return (K * N1) % 2 == 0;
 }
 // Which stream are the parameters uploaded on?  The first kernel that reads them runs on the side stream for the two
 // broadcast paths (per-row / per-column evaluation) and for the tile path (stage tables); only the fallback row kernel
@@ -365,6 +367,7 @@ RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P
   // and the double-buffered side stream overlaps the evaluation of batch k+1 with the stream of batch k.
   const size_t line_bytes = row_count * r.replicas * 64;
   r.batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(line_bytes, 1)));
+  r.batch = std::min<size_t>(r.batch, 65535 / (aos6 ? 1 : kOpWidth[op]));  // grid.z of the store stream = batch x planes
   return r;
 }
 
@@ -550,7 +553,16 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
                 size_t row_begin, size_t row_count, int layout, hipStream_t s, int what = 0, double accuracy = 0.0,
                 double* d_stats = nullptr) {
   if (row_count == 0 || N1 == 0) return INFLX_OK;
-  if (P > 65535) return fail(INFLX_ERR_SHAPE, "at most 65535 parameter rows per launch (got %zu)", P);
+  if (P > 65535) {
+    // grid.z (and grid.y of the evaluation kernels) carries the parameter row: longer parameter axes take several launches
+    for (size_t p0 = 0; p0 < P; p0 += 65535) {
+      const size_t pb = std::min<size_t>(65535, P - p0);
+      double* sub = d_out ? reinterpret_cast<double*>(reinterpret_cast<char*>(d_out) + p0 * row_count * N1 * kOpBytes[op]) : nullptr;
+      const int rc = launch_grid(m, op, d_params + p0 * m->n_par, pb, sub, ss, N0, N1, row_begin, row_count, layout, s, what, accuracy, d_stats);
+      if (rc) return rc;
+    }
+    return INFLX_OK;
+  }
   InflxSweepArgs a;
   memset(&a, 0, sizeof a);
   a.out = d_out;
@@ -1077,7 +1089,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
   const size_t total = P * row_count * row_bytes;
-  bool whole = total <= whole_result_limit() && P <= 65535;
+  bool whole = total <= whole_result_limit();
   if (whole && total > m->d_whole_cap) {
     if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
     m->d_whole = nullptr;

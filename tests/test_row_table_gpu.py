@@ -232,3 +232,31 @@ def test_dominant_only_timing_refuses_several_batches(hyp, gpu_lib):
     ms = lib.sweep_device_timed(gpu_lib.OP_COMPLETE, rows[:4], out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream, repeats=2, dominant_only=True)
     assert ms > 0
     check_block(out[:4], rows[:4], spec.extent, n0, "after dominant-only timing")
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_more_than_65535_parameter_rows_in_one_call(name, gpu_lib):
+    """A long parameter axis on a small grid (a parameter scan): 70 000 rows in one call.  grid.z / grid.y carry the
+    parameter row, so the library cuts the axis into launches of at most 65 535 rows (and the store streams into batches
+    of at most 65 535 images); sampled parameter rows equal the same sweep issued alone, for the AoS result, a
+    single-value result and the SoA planes."""
+    import workloads
+
+    spec, art = workloads.artifact_for(name)
+    lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    P, n0, n1 = 70000, 4, 6
+    rng = np.random.default_rng(65535)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.8, 1.25, size=(P, len(spec.args)))
+    ss = np.array(spec.extent).reshape(2, 2)
+    sample = [0, 1, 65534, 65535, 65536, P - 1] + [int(v) for v in rng.integers(0, P, 6)]
+    for op, layout, shape in ((gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_AOS, (P, n0, n1, 6)), (gpu_lib.OP_EPSILON_V, gpu_lib.LAYOUT_AOS, (P, n0, n1)), (gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_SOA, (P, 6, n0, n1))):
+        got = lib.sweep_host(op, rows, ss, n0, n1, layout=layout)
+        assert got.shape == shape
+        for k in sample:
+            alone = lib.sweep_host(op, rows[k], ss, n0, n1, layout=layout)
+            assert np.array_equal(got[k], alone, equal_nan=True), (name, op, layout, k)
+    # the fused summary over the whole axis equals numpy over the arrays
+    from inflatox_amd.distributed import numpy_summary
+
+    stats, ref = lib.sweep_stats(rows, ss, n0, n1), numpy_summary(lib.sweep_host(gpu_lib.OP_COMPLETE, rows, ss, n0, n1))
+    assert np.array_equal(stats["count"], ref["count"]) and np.array_equal(stats["min"], ref["min"]) and np.array_equal(stats["max"], ref["max"])
