@@ -10,11 +10,19 @@ size is built on it.  The arrays are ordinary writeable numpy arrays; nothing is
 writes every element, so no zeroing is needed.
 
 ``INFLX_RESULT_POOL_MB`` (default 1024) bounds the memory the pool keeps; 0 switches it off (plain ``np.zeros``).
-Arrays above half of the bound are never pooled.
+Arrays above half of the bound are never pooled.  When a returning buffer does not fit, the buffers that have been lying
+in the pool longest are released first (a scan that moves on to another grid size does not stay stuck with the old one).
+
+Locking: the finalizer of a result array can run at any point at which the garbage collector runs -- also while this
+module holds its lock on the same thread (an allocation inside the locked region may start a collection that finalises
+another pooled array sitting in a reference cycle).  The finalizer therefore takes no lock at all: it appends the buffer
+to a ``collections.deque`` (atomic under the GIL), and ``result_array`` / ``held_bytes`` move the returned buffers into
+the size-indexed free lists under the (re-entrant) lock.
 """
 
 from __future__ import annotations
 
+import collections
 import mmap
 import os
 import threading
@@ -25,21 +33,53 @@ import numpy as np
 _LIMIT = max(0, int(os.environ.get("INFLX_RESULT_POOL_MB", "1024"))) << 20
 _PER_SIZE = 4
 
-_lock = threading.Lock()
-_free: dict[int, list] = {}
+_lock = threading.RLock()
+_returned: collections.deque = collections.deque()  # (buf, nbytes) pushed by finalizers, no lock taken
+_free: dict[int, collections.deque] = {}  # nbytes -> deque of (age, buf), oldest first
 _held = 0
+_age = 0
 
 
 def _give_back(buf, nbytes: int) -> None:
-    """Called when the last numpy view of a pooled buffer has died."""
+    """Called when the last numpy view of a pooled buffer has died.  Lock-free on purpose (see the module text)."""
+    _returned.append((buf, nbytes))
+
+
+def _evict_oldest(keep_size: int) -> bool:
+    """Release the buffer that has been in the pool longest (any size but ``keep_size`` first).  Lock held."""
     global _held
-    with _lock:
-        lst = _free.setdefault(nbytes, [])
-        if len(lst) < _PER_SIZE and _held + nbytes <= _LIMIT:
-            lst.append(buf)
+    best = None
+    for size, lst in _free.items():
+        if lst and size != keep_size and (best is None or lst[0][0] < _free[best][0][0]):
+            best = size
+    if best is None and _free.get(keep_size):
+        best = keep_size
+    if best is None:
+        return False
+    _free[best].popleft()  # the mapping is unmapped when this last reference goes
+    _held -= best
+    return True
+
+
+def _drain() -> None:
+    """Move the buffers finalizers have returned into the free lists.  Lock held."""
+    global _held, _age
+    while True:
+        try:
+            buf, nbytes = _returned.popleft()
+        except IndexError:
+            return
+        lst = _free.get(nbytes)
+        if lst is None:
+            lst = _free[nbytes] = collections.deque()
+        if len(lst) >= _PER_SIZE or nbytes > _LIMIT // 2:
+            continue  # not pooled: unmapped when `buf` goes out of scope (no explicit close(): the dying owner array may still hold its buffer export)
+        while _held + nbytes > _LIMIT and _evict_oldest(nbytes):
+            pass
+        if _held + nbytes <= _LIMIT:
+            _age += 1
+            lst.append((_age, buf))
             _held += nbytes
-    # not pooled: the mapping is unmapped when this last reference goes (no explicit close(): the dying owner array may
-    # still hold its buffer export at this point)
 
 
 def result_array(shape, dtype=np.float64) -> np.ndarray:
@@ -53,9 +93,10 @@ def result_array(shape, dtype=np.float64) -> np.ndarray:
         return np.zeros(shape, dtype=dtype)
     buf = None
     with _lock:
+        _drain()
         lst = _free.get(nbytes)
         if lst:
-            buf = lst.pop()
+            buf = lst.pop()[1]  # the most recently returned one: its pages are the likeliest to be resident
             _held -= nbytes
     if buf is None:
         buf = mmap.mmap(-1, nbytes, flags=mmap.MAP_PRIVATE | mmap.MAP_ANONYMOUS)
@@ -66,4 +107,5 @@ def result_array(shape, dtype=np.float64) -> np.ndarray:
 
 def held_bytes() -> int:
     with _lock:
+        _drain()
         return _held

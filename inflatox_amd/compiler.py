@@ -212,14 +212,14 @@ class CompilationArtifact:
             print(f"{old} -> {new}")
 
 
-_COMMENT = re.compile(r'"(?:\\.|[^"\\])*"|//[^\n]*|/\*.*?\*/', re.S)
+_COMMENT = re.compile(r'"(?:\\.|[^"\\])*"|(?<![0-9A-Za-z_])\'(?:\\.|[^\'\\])*\'|//[^\n]*|/\*.*?\*/', re.S)
 
 
 def _code_only(source: str) -> str:
-    """C/C++ source without comments and blank lines (string literals kept): what the content tag of a code object
+    """C/C++ source without comments and blank lines (string and character literals kept): what the content tag of a code object
     hashes, so that editing a comment in the kernel sources neither rebuilds every model nor orphans the profiles
     that are stamped with the tag."""
-    text = _COMMENT.sub(lambda m: m.group(0) if m.group(0).startswith('"') else " ", source)
+    text = _COMMENT.sub(lambda m: m.group(0) if m.group(0)[0] in "\"'" else " ", source)
     return "\n".join(ln.rstrip() for ln in text.splitlines() if ln.strip())
 
 

@@ -215,6 +215,7 @@ struct inflx_model {
     size_t cap = 0, count = 0;      // doubles
     hipStream_t stream = nullptr;   // stream the upload was ordered on
     hipEvent_t last_use = nullptr;  // recorded behind the last kernel that reads `dev`
+    hipStream_t last_reader = nullptr;  // stream `last_use` was recorded on
     bool in_flight = false;
   };
   static constexpr int kParamSlots = 4;
@@ -282,9 +283,24 @@ int acquire_params(inflx_model* m, const double* p, size_t count, hipStream_t s,
 // every kernel that reads the current parameter slot has been enqueued, the last of them on `reader`
 int release_params(inflx_model* m, hipStream_t reader) {
   inflx_model::ParamSlot& cur = m->pslot[m->pcur];
+  if (!cur.last_use) return INFLX_OK;  // nothing was ever uploaded into this slot
+  // One event per slot: when the readers of an earlier call ran on another stream (a cache hit from a different caller
+  // stream), the new reader first waits for them, so that the re-recorded event still stands behind every reader.
+  if (cur.in_flight && cur.last_reader != reader) HIP_TRY(hipStreamWaitEvent(reader, cur.last_use, 0));
   HIP_TRY(hipEventRecord(cur.last_use, reader));
+  cur.last_reader = reader;
   cur.in_flight = true;
   return INFLX_OK;
+}
+
+// The same on an error path: kernels that were enqueued before the failure may still read the slot, so it must be
+// marked in flight all the same; the first error is the one reported.
+int release_params_after(inflx_model* m, hipStream_t reader, int rc) {
+  if (rc == INFLX_OK) return release_params(m, reader);
+  const std::string first = g_last_error;
+  (void)release_params(m, reader);
+  g_last_error = first;
+  return rc;
 }
 
 // validate_lib + validiate_p (src/anguelova.rs:55-79) and the Hesse2D guard (hesse_bindings.rs:203)
@@ -927,9 +943,8 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
   if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   if (row_count && N1) {
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, INFLX_AOS, s, 0, 0.0, m->d_stats);
-    if (rc) return rc;
   }
-  if ((rc = release_params(m, eval))) return rc;
+  if ((rc = release_params_after(m, eval, rc))) return rc;
   HIP_TRY(hipMemcpyAsync(summary, m->d_stats, sizeof *summary, hipMemcpyDeviceToHost, eval));
   HIP_TRY(hipStreamSynchronize(eval));
   if (eval != s) HIP_TRY(hipStreamSynchronize(s));
@@ -961,8 +976,8 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
-  if ((rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s))) return rc;
-  return release_params(m, last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side);
+  rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
+  return release_params_after(m, last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side, rc);
 }
 
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
@@ -980,7 +995,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   for (int k = 0; k < repeats; ++k) {
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s,
                      dominant_only ? 2 : 0);
-    if (rc) return rc;
+    if (rc) return release_params_after(m, reader, rc);
   }
   HIP_TRY(hipEventRecord(m->t1, s));
   if ((rc = release_params(m, reader))) return rc;
@@ -1113,7 +1128,11 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     // stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the resident
     // frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
-    if (rc) return rc;
+    if (rc) {  // kernels enqueued before the failure may still read the parameter slot
+      (void)hipStreamSynchronize(m->side);
+      (void)hipStreamSynchronize(m->stream);
+      return rc;
+    }
     advise_huge_pages(out, total);
     // helpers may only walk the destination while the copy is under way if their page touch is a real atomic
     // read-modify-write (touch_range); elsewhere everything is made resident before the copy starts
@@ -1184,6 +1203,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   // on every exit -- errors included -- nothing may still be writing to the caller's buffer
   auto drain = [&] {
     if (ready.valid()) ready.wait();
+    (void)hipStreamSynchronize(m->side);
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamSynchronize(m->copy_stream);
   };

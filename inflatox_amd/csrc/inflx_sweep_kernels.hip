@@ -359,7 +359,8 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     InflxModelValues mv;
     bool ok = true;
     inflx_stage_point_quick(x0, x1, A, U, Rs[r], C, mv, ok);
-    if (__builtin_amdgcn_ballot_w64(!ok) != 0) {  // wave-uniform
+    // (lanes past N1 hold zeros for their column values and fail every acceptance test: they do not vote)
+    if (__builtin_amdgcn_ballot_w64(!ok && in_range) != 0) {  // wave-uniform
       redo |= uint64_t(1) << r;
       ++streak;
       continue;

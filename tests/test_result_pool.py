@@ -54,3 +54,36 @@ def test_overflowing_the_pool_is_silent(recwarn):
     gc.collect()
     assert pool.held_bytes() <= held + pool._PER_SIZE * 64 * 64 * 48
     assert not [w for w in recwarn.list if "Unraisable" in str(w.category)]
+
+
+def test_finalizer_never_takes_the_lock():
+    """A result array can be finalised (cyclic GC) while this thread is inside the pool's locked region; the finalizer
+    must not wait for the lock (a non-reentrant lock there hangs the process)."""
+    a = pool.result_array((33, 31, 6))
+    cycle = [a]
+    cycle.append(cycle)  # only the cyclic collector can free it
+    del a
+    with pool._lock:
+        del cycle
+        gc.collect()  # runs _give_back on this thread, inside the locked region
+    assert pool.held_bytes() >= 33 * 31 * 48
+
+
+def test_stale_sizes_make_room_for_new_ones(monkeypatch):
+    """Once the bound is reached the buffers that have been in the pool longest are released, so a scan that moves on
+    to another grid size is pooled again."""
+    gc.collect()
+    pool.held_bytes()
+    monkeypatch.setattr(pool, "_LIMIT", pool.held_bytes() + 3 * 100 * 100 * 48 + 1000)
+    old = [pool.result_array((100, 100, 6)) for _ in range(3)]
+    del old
+    gc.collect()
+    before = pool.held_bytes()
+    new = pool.result_array((100, 101, 6))
+    addr = _addr(new)
+    del new
+    gc.collect()
+    assert pool.held_bytes() <= pool._LIMIT
+    assert pool.held_bytes() >= before - 100 * 100 * 48  # at most one old buffer went
+    again = pool.result_array((100, 101, 6))
+    assert _addr(again) == addr  # the new size is pooled although the pool was full of the old one

@@ -291,6 +291,9 @@ def test_content_tag_ignores_comments_in_the_kernel_sources():
     assert _code_only(a) == _code_only(b)
     assert '"a//b /* c */"' in _code_only(a)
     assert _code_only(a) != _code_only(a.replace("return 1", "return 2"))
+    # character literals do not flip the in-string parity, digit separators are not literals
+    c = "char q = '\"'; // gone\nconst char* s = \"// kept\"; char e = '\\''; int n = 1'000; // gone too\n"
+    assert _code_only(c) == "char q = '\"';\nconst char* s = \"// kept\"; char e = '\\''; int n = 1'000;"
 
 
 @pytest.mark.parametrize("name", MODELS)
