@@ -262,7 +262,7 @@ class Compiler:
       0.592 -> 0.519 ms per 4096^2 sweep on MI355X); ``True`` / ``False`` force it.
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
-    (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order, spherical
+    (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer order; real orders are refused; spherical
     ones of integer order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
     print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
     """

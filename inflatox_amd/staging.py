@@ -149,17 +149,19 @@ class HIPInflatoxPrinter(C99CodePrinter):
         return super()._print_Pow(expr)
 
     # -- special functions (reference: GSLInflatoxPrinter, compiler.py:123-212 -> gsl_sf_bessel_*) ------
-    # device counterparts live in csrc/inflx_sf.h; integer orders only
+    # device counterparts live in csrc/inflx_sf.h; integer orders only (real orders are refused)
     _CYLINDRICAL = {"besselj": "J", "bessely": "Y", "besseli": "I", "besselk": "K"}
     _SPHERICAL = {"jn": "j", "yn": "y"}
 
     def _bessel(self, expr, letter, named_orders, general):
         nu, arg = expr.args
         if not (nu.is_number and nu.is_integer):
-            # real or symbolic order: gsl_sf_bessel_{J,Y,I,K}nu(nu, x) in the reference (nu >= 0)
-            if letter not in "JYIK":
-                raise NotImplementedError(f"{expr.func.__name__} of non-integer order {nu}: the reference has no such function either (compiler.py:199-212)")
-            return f"inflx_sf_bessel_{letter}nu({self._print(nu)}, {self._print(arg)})"
+            # real or symbolic order: gsl_sf_bessel_{J,Y,I,K}nu(nu, x) in the reference (compiler.py:199-212); there is no
+            # device counterpart in this package, and a silent substitute would be worse than a refusal
+            raise NotImplementedError(
+                f"{expr.func.__name__} of non-integer order {nu}: Bessel functions of real order have no device implementation "
+                "(integer orders, spherical functions of integer order and 0F1/1F1/2F1/2F0 do)"
+            )
         n = int(nu)
         x = self._print(arg)
         if n in named_orders:

@@ -184,29 +184,10 @@ def ik():
         table(f"INFLX_SF_K{nu}_FAR", far, f"exp(x) sqrt(x) K{nu}(x), x >= 8, t = 16/x - 1")
 
 
-def temme():
-    """Temme's gamma-function combinations for the real-order routines, on mu in [-1/2, 1/2] (t = 2 mu):
-    gam1 = (1/Gamma(1-mu) - 1/Gamma(1+mu)) / (2 mu),  gam2 = (1/Gamma(1-mu) + 1/Gamma(1+mu)) / 2."""
-
-    def gam1(t):
-        mu = t / 2
-        if abs(mu) < mp.mpf("1e-25"):
-            return -mp.euler
-        return (mp.rgamma(1 - mu) - mp.rgamma(1 + mu)) / (2 * mu)
-
-    def gam2(t):
-        mu = t / 2
-        return (mp.rgamma(1 - mu) + mp.rgamma(1 + mu)) / 2
-
-    table("INFLX_SF_GAM1", gam1, "(1/Gamma(1-mu) - 1/Gamma(1+mu))/(2 mu), |mu| <= 1/2, t = 2 mu")
-    table("INFLX_SF_GAM2", gam2, "(1/Gamma(1-mu) + 1/Gamma(1+mu))/2, |mu| <= 1/2, t = 2 mu")
-
-
 def main():
     jy_small()
     jy_large()
     ik()
-    temme()
     lines = [
         "// Generated by scripts/make_sf_tables.py -- do not edit.",
         "// Chebyshev coefficients (f ~ c[0]/2 + sum_{j>=1} c[j] T_j(t)) fitted to 50-digit mpmath values; see the",

@@ -217,13 +217,13 @@ def bessel_toy():
     return [phi, theta], [[1, 0], [0, L**2 * (1 + phi**2)]], potential
 
 
-def bessel_real():
-    """Bessel functions of real order (a fixed one and a parameter) and 0F1: the functions the reference reaches
-    through gsl_sf_bessel_*nu and gsl_sf_hyperg_0F1.  The parameter nu must be >= 2 for the Hesse matrix
-    (its second derivatives bring in K_(nu-2); GSL, like the device functions, rejects negative orders)."""
+def bessel_0f1():
+    """Integer-order Bessel functions of both kinds and 0F1 in one potential: the functions the reference reaches
+    through gsl_sf_bessel_Jn / _Kn and gsl_sf_hyperg_0F1 (Bessel functions of real order have no device
+    implementation and are refused by the transpiler)."""
     phi, theta = sp.symbols("phi theta")
-    m, nu = sp.symbols("m nu")
-    shape = 3 + sp.besselj(sp.Rational(5, 2), phi) + sp.besselk(nu, phi + 1) + sp.hyper([], [sp.Rational(3, 2)], -(phi**2) / 4)
+    m, c = sp.symbols("m c")
+    shape = 3 + sp.besselj(2, phi) + sp.besselk(1, phi + 1) + sp.hyper([], [c], -(phi**2) / 4)
     potential = m**2 * shape * (1 + sp.cos(theta) / 10)
     return [phi, theta], [[1, 0], [0, 1 + phi**2]], potential
 
