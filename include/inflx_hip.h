@@ -120,6 +120,18 @@ int inflx_validate_basis_on_domain(inflx_model* model, const uint32_t* num_point
                                    size_t n_p, const double* start_stop, double accuracy);
 
 /*
+ * The per-point operations of src/anguelova.rs:99-171 (`mod ops`) applied to GIVEN model values instead of values the
+ * kernels evaluate from a model: `values` is (n,5) -- V, v00, v10, v11, grad_norm_squared, what Potential / Hesse2D
+ * return (hesse_bindings.rs:52-57,106-110,213-231) --, `out` is (n,9): [0..5] ops::complete_analysis (:103-135),
+ * [6] ops::consistency_only (:157-163), [7] ops::consistency_rapidturn_only (:143-154), [8] ops::epsilon_v_only
+ * (:138-140).  The model's own functions are not called.  `ieee_only` = 0 evaluates complete_analysis the way the
+ * sweep kernels do (divisions without special-case handling where every operand is in mid range, csrc/inflx_ops.h),
+ * != 0 with the compiler's IEEE divisions throughout; the two must agree bit for bit on every input, and both are
+ * what the parity tests compare with the oracle on arbitrary tuples (specials, zeros, denormals, random bit patterns).
+ */
+int inflx_ops_on_values(inflx_model* model, const double* values, size_t n, double* out, int ieee_only);
+
+/*
  * Generalised sweep, host result.  P parameter rows (p is (P,n_p)), grid rows
  * [row_begin,row_begin+row_count) of the N0 x N1 grid, result written to the host buffer `out`
  * of P*row_count*N1*K doubles in `layout`.  Rows are processed in device-sized chunks and copied

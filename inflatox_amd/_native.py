@@ -59,6 +59,7 @@ SIGNATURES = {
     "inflx_synchronize": (C.c_int, [C.c_void_p]),
     "inflx_sweep_plan": (C.c_int, [C.c_void_p, C.c_int, _SIZE, _SIZE, _SIZE, C.c_int, C.POINTER(C.c_uint32)]),
     "inflx_basis_on_points": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _SIZE, _DP]),
+    "inflx_ops_on_values": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, C.c_int]),
     "inflx_validate_basis_at_random": (C.c_int, [C.c_void_p, C.c_uint64]),
     "inflx_validate_basis_on_domain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _SIZE, _DP, _SIZE, _DP, C.c_double]),
 }
@@ -273,6 +274,18 @@ class InflatoxDevLib:
             raise InflatoxShapeError(f"point array should have shape (n,2) (got {x.shape})")
         out = np.zeros((x.shape[0], 7))
         _check(self._lib.inflx_basis_on_points(self._h, _ptr(p), p.size, _ptr(x), x.shape[0], _ptr(out)))
+        return out
+
+    def ops_on_values(self, values, ieee_only: bool = False) -> np.ndarray:
+        """(n,9): ``ops::complete_analysis`` [0..5], ``consistency_only`` [6], ``consistency_rapidturn_only`` [7] and
+        ``epsilon_v_only`` [8] (src/anguelova.rs:99-163) of n given records (V, v00, v10, v11, |dV|^2) -- the model's own
+        functions are not evaluated.  ``ieee_only``: the compiler's IEEE divisions throughout instead of the sweep
+        kernels' spelling (bit-identical by construction; the tests assert it)."""
+        values = _f64(values, "values")
+        if values.ndim != 2 or values.shape[1] != 5:
+            raise InflatoxShapeError(f"values array should have shape (n,5) (got {values.shape})")
+        out = np.zeros((values.shape[0], 9))
+        _check(self._lib.inflx_ops_on_values(self._h, _ptr(values), values.shape[0], _ptr(out), int(bool(ieee_only))))
         return out
 
     def validate_basis_at_random(self, seed: int = 0) -> None:

@@ -223,6 +223,24 @@ def _code_only(source: str) -> str:
     return "\n".join(ln.rstrip() for ln in text.splitlines() if ln.strip())
 
 
+def _tile_kernel_scratch_bytes(code_object: str) -> int:
+    """Scratch (spill) bytes per lane of inflx_sweep_tile_complete, from the code object's metadata note; a large value
+    when it cannot be read (no llvm-readelf next to hipcc), so that the caller stays with the conservative build."""
+    tool = os.path.join(os.path.dirname(os.path.realpath(hipcc_path())), "..", "lib", "llvm", "bin", "llvm-readelf")
+    if not os.path.exists(tool):
+        tool = "/opt/rocm/lib/llvm/bin/llvm-readelf"
+    try:
+        notes = subprocess.run([tool, "--notes", code_object], capture_output=True, text=True, timeout=60).stdout
+    except (OSError, subprocess.SubprocessError):
+        return 1 << 30
+    for block in notes.split("- .agpr_count:"):
+        if re.search(r"\.name:\s+inflx_sweep_tile_complete\s", block):
+            m = re.search(r"\.private_segment_fixed_size:\s+(\d+)", block)
+            if m:
+                return int(m.group(1))
+    return 1 << 30
+
+
 def _cache_dir() -> str:
     d = os.environ.get("INFLATOX_AMD_CACHE") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "_jit_cache")
     os.makedirs(d, exist_ok=True)
@@ -261,6 +279,13 @@ class Compiler:
       when at least ``HOIST_MIN_QUOTIENTS`` divisions of the five sweep values qualify (D5: 29 of 53 divisions,
       0.592 -> 0.519 ms per 4096^2 sweep on MI355X); ``True`` / ``False`` force it.
 
+    * ``tan_shortcut`` (default 0 = off; ``None`` reads the environment variable ``INFLX_TAN_SHORTCUT``): the epilogue's
+      ``tan(atan(t))``, t = |v10/v00| (src/anguelova.rs:128,132), is taken as ``t`` itself wherever ``t <= tan_shortcut``.
+      The reference's two libm calls return t(1 + e) with |e| <~ (t + 1/t)*2^-53, so the results differ from the default
+      mode's by at most ~(tan_shortcut + 1)*2^-53 relative on ``tan(delta)`` -- far inside the 1e-10 bar, and closer to the
+      exact value than the reference itself -- but they are no longer OCML's tan of OCML's atan bit for bit; a wavefront
+      all of whose points qualify skips the ~55 instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
+
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer order; real orders are refused; spherical
     ones of integer order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
@@ -270,6 +295,8 @@ class Compiler:
     #: `hoist_reciprocals=None` turns the hoisted-reciprocal division on when the five sweep values contain at least
     #: this many per-point quotients by a denominator of an earlier stage
     HOIST_MIN_QUOTIENTS = 16  # measured at 4096^2: D5 (29) 0.592 -> 0.519 ms; EGNO (12) 0.457 -> 0.465 ms; doc (1) 0.263 -> 0.269 ms
+    #: three wavefronts per SIMD are kept when the tile kernel of complete_analysis needs at most this much scratch per lane
+    MAX_SCRATCH_FOR_THREE_WAVES = 128
     c_prefix = "inflx_auto_"
     lib_prefix = "libinflx_auto_"
 
@@ -307,6 +334,7 @@ class Compiler:
         exact_constants: bool = False,
         regroup: bool = False,
         hoist_reciprocals: bool | None = None,
+        tan_shortcut: float | None = None,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -322,6 +350,11 @@ class Compiler:
         self.staged = staged
         self.regroup = regroup
         self.hoist_reciprocals = hoist_reciprocals
+        if tan_shortcut is None:
+            tan_shortcut = float(os.environ.get("INFLX_TAN_SHORTCUT", "0") or 0)
+        if tan_shortcut < 0 or tan_shortcut != int(tan_shortcut) or tan_shortcut >= 2**17:
+            raise ValueError("tan_shortcut must be a whole number in [0, 2^17): the largest |v10/v00| for which tan(atan(t)) is taken as t")
+        self.tan_shortcut = int(tan_shortcut)
         self.constants = dict(_EXACT_CONSTANTS if exact_constants else _REFERENCE_CONSTANTS)
         self.hipcc_opts = list(compiler_flags) if compiler_flags is not None else list(self.default_hipcc_flags)
         self.symbol_dict = None
@@ -450,26 +483,54 @@ class Compiler:
                 rows //= 2
             if rows != 32:
                 opts.append(f"-DINFLX_TILE_ROWS={rows}")
-        h.update(" ".join(opts).encode())
-        tag = h.hexdigest()[:20]
+        if self.tan_shortcut and not any(o.startswith("-DINFLX_TAN_SHORTCUT_MAX") for o in opts):
+            opts.append(f"-DINFLX_TAN_SHORTCUT_MAX={self.tan_shortcut}")
         cache = _cache_dir()
-        cached = os.path.join(cache, f"{tag}.hsaco")
-        header_path = os.path.join(cache, f"{tag}.h")
-        log = b""
-        code = 0
-        if not os.path.exists(cached):
-            # several ranks may compile the same model at once: every file appears atomically
-            tmp_hdr = header_path + f".{os.getpid()}.tmp"
-            with open(tmp_hdr, "w") as fh:
-                fh.write(header_text)
-            os.replace(tmp_hdr, header_path)
-            tmp_out = cached + f".{os.getpid()}.tmp"
-            cmd = [hipcc_path(), *opts, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
-            proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-            log, code = proc.stdout, proc.returncode
-            if code == 0:
-                os.replace(tmp_out, cached)
-        return cached, header_path, log, code
+
+        def build(options):
+            hh = h.copy()
+            hh.update(" ".join(options).encode())
+            tag = hh.hexdigest()[:20]
+            cached = os.path.join(cache, f"{tag}.hsaco")
+            header_path = os.path.join(cache, f"{tag}.h")
+            log, code = b"", 0
+            if not os.path.exists(cached):
+                # several ranks may compile the same model at once: every file appears atomically
+                tmp_hdr = header_path + f".{os.getpid()}.tmp"
+                with open(tmp_hdr, "w") as fh:
+                    fh.write(header_text)
+                os.replace(tmp_hdr, header_path)
+                tmp_out = cached + f".{os.getpid()}.tmp"
+                cmd = [hipcc_path(), *options, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
+                proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                log, code = proc.stdout, proc.returncode
+                if code == 0:
+                    os.replace(tmp_out, cached)
+            return cached, header_path, log, code
+
+        if any(o.startswith("-DINFLX_MIN_WAVES") for o in opts):
+            return build(opts)
+        # Occupancy of the tile kernels.  They are bound by FP64 VALU issue, and two wavefronts per SIMD leave the pipe idle
+        # ~14 % of the time (SQ counters, D5); three fill it.  Three need <= 168 vector registers: the light models are
+        # below that anyway, a heavy one (D5: 194) is asked to fit (__launch_bounds__(256, 3)) and accepted when the
+        # register allocator gets there with a handful of spilled values (D5: 13 registers, 3 scratch accesses per grid
+        # row, 15.1 -> 14.3 ms for 4096^2 x 32); a model that would spill in earnest keeps two (the choice is cached).
+        three = opts + ["-DINFLX_MIN_WAVES=3"]
+        hh = h.copy()
+        hh.update(" ".join(three).encode())
+        verdict_path = os.path.join(cache, f"{hh.hexdigest()[:20]}.waves")
+        verdict = open(verdict_path).read().strip() if os.path.exists(verdict_path) else None
+        if verdict != "2":
+            result = build(three)
+            if result[3] == 0 and verdict is None:
+                verdict = "3" if _tile_kernel_scratch_bytes(result[0]) <= self.MAX_SCRATCH_FOR_THREE_WAVES else "2"
+                tmp = verdict_path + f".{os.getpid()}.tmp"
+                with open(tmp, "w") as fh:
+                    fh.write(verdict + "\n")
+                os.replace(tmp, verdict_path)
+            if verdict == "3" or result[3] != 0:
+                return result
+        return build(opts + ["-DINFLX_MIN_WAVES=2"])
 
     def compile(self) -> CompilationArtifact:
         if not self.silent:

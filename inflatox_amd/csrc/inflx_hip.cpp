@@ -172,6 +172,7 @@ struct inflx_model {
   hipFunction_t rows[INFLX_OP_COUNT] = {};
   hipFunction_t traj[INFLX_OP_COUNT] = {};
   hipFunction_t basis_points = nullptr;
+  hipFunction_t ops_on_values = nullptr;
   hipFunction_t rowvals[INFLX_OP_COUNT] = {};
   hipFunction_t rowstream6 = nullptr;
   hipFunction_t rowstream_planes = nullptr;
@@ -813,6 +814,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_basis_points", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
+  if (hipModuleGetFunction(&m->ops_on_values, m->module, "inflx_ops_on_values") != hipSuccess) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_ops_on_values", artefact_path);
+    return bail(INFLX_ERR_SYMBOL);
+  }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
       hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) {
@@ -1028,6 +1033,32 @@ int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const dou
   void* params[] = {&a};
   const size_t gx = (n + m->info.tile_cols - 1) / m->info.tile_cols;
   HIP_TRY(hipModuleLaunchKernel(m->basis_points, (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
+  HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+int inflx_ops_on_values(inflx_model* m, const double* values, size_t n, double* out, int ieee_only) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (n == 0) return INFLX_OK;
+  if (!values || !out) return fail(INFLX_ERR_ARG, "values / output pointer is NULL");
+  HIP_TRY(hipSetDevice(m->device));
+  const size_t in_bytes = n * 5 * sizeof(double), out_bytes = n * 9 * sizeof(double);
+  int rc;
+  if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
+  if ((rc = ensure_chunk(m, 1, in_bytes))) return rc;
+  HIP_TRY(hipMemcpyAsync(m->d_chunk[1], values, in_bytes, hipMemcpyHostToDevice, m->stream));
+  InflxTrajectoryArgs a;
+  memset(&a, 0, sizeof a);
+  a.out = static_cast<double*>(m->d_chunk[0]);
+  a.points = static_cast<const double*>(m->d_chunk[1]);
+  a.n = n;
+  a.P = 1;
+  a.reserved = ieee_only ? 1u : 0u;
+  void* params[] = {&a};
+  const size_t gx = (n + m->info.tile_cols - 1) / m->info.tile_cols;
+  if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "too many records for one launch");
+  HIP_TRY(hipModuleLaunchKernel(m->ops_on_values, (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
   HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return INFLX_OK;

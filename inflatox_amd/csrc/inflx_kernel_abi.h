@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 13u
+#define INFLX_KERNEL_ABI 14u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -68,7 +68,7 @@ struct InflxTrajectoryArgs {
   const double* points;  // [n][2]
   uint64_t n;
   uint32_t P;
-  uint32_t reserved;
+  uint32_t reserved;  // inflx_ops_on_values: 1 = IEEE spelling of the divisions only (points = n records of 5 model values there)
   double accuracy;
 };
 

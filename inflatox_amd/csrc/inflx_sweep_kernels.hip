@@ -62,6 +62,10 @@
 #ifndef INFLX_U_IN_LDS
 #define INFLX_U_IN_LDS (INFLX_NU > 8)
 #endif
+// tile kernels: the epilogue's polynomial coefficients in LDS instead of 68 resident vector registers
+#ifndef INFLX_EPILOGUE_CONSTANTS_IN_LDS
+#define INFLX_EPILOGUE_CONSTANTS_IN_LDS 1
+#endif
 
 static_assert(INFLX_DIM == 2, "the sweep kernels need a two-field model (Hesse2D, hesse_bindings.rs:203)");
 
@@ -98,12 +102,14 @@ struct OpWidth {
   static constexpr int K = (OP == INFLX_OP_COMPLETE) ? 6 : (OP == INFLX_OP_RAW ? 5 : 1);
 };
 
-template <int OP>
-__device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, [[maybe_unused]] double accuracy = 0.0) {
+// TABLE / `kc`: the polynomial coefficients of the epilogue's atan / tan come from a table in LDS (tile kernels) instead
+// of literals (inflx_ops.h)
+template <int OP, bool TABLE = false>
+__device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, [[maybe_unused]] double accuracy = 0.0, [[maybe_unused]] const double* kc = nullptr) {
   if constexpr (OP == INFLX_OP_QDIF) {
     o[0] = inflx_op_flag_quantum_diff(mv, accuracy) ? 1.0 : 0.0;
   } else if constexpr (OP == INFLX_OP_COMPLETE) {
-    inflx_op_complete_analysis(mv, o);
+    inflx_op_complete_analysis<TABLE>(mv, o, kc);
   } else if constexpr (OP == INFLX_OP_CONSISTENCY) {
     o[0] = inflx_op_consistency_only(mv);
   } else if constexpr (OP == INFLX_OP_RAPIDTURN) {
@@ -116,6 +122,22 @@ __device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, 
     o[2] = mv.v10;
     o[3] = mv.v11;
     o[4] = mv.g;
+  }
+}
+
+// The per-point operation with its divisions spelled without special-case handling (inflx_ops.h); false = this point
+// needs the IEEE spelling.  Only complete_analysis has such a variant: the single-quantity operations are three or four
+// divisions on an 8-byte store stream.
+template <int OP, bool TABLE = false>
+__device__ __forceinline__ bool apply_op_quick(const InflxModelValues& mv, double* o, [[maybe_unused]] double accuracy = 0.0, [[maybe_unused]] const double* kc = nullptr) {
+#ifndef INFLX_EXPERIMENT_IEEE_EPILOGUE  // (A/B experiments: the compiler's divisions in the hot loop as well)
+  if constexpr (OP == INFLX_OP_COMPLETE) {
+    return inflx_op_complete_analysis_quick<TABLE>(mv, o, kc);
+  } else
+#endif
+  {
+    apply_op<OP, TABLE>(mv, o, accuracy, kc);
+    return true;
   }
 }
 
@@ -218,6 +240,18 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   if constexpr (STATS) stat_init(acc);
   __shared__ double Rs[kTileRows][kNR];
   __shared__ __attribute__((aligned(16))) double tbuf[kThreads / kWave][kWave * 6];
+#if INFLX_EPILOGUE_CONSTANTS_IN_LDS
+  // the 34 polynomial coefficients of the epilogue's atan / tan: read back as LDS broadcasts straight into the
+  // accumulator of each Horner step instead of living in 68 vector registers across the row loop (inflx_ops.h)
+  __shared__ double epilogue_constants[kInflxEpilogueConstants];
+  if (OP == INFLX_OP_COMPLETE && threadIdx.x < (unsigned)kInflxEpilogueConstants)
+    epilogue_constants[threadIdx.x] = threadIdx.x < (unsigned)kInflxAtanTerms ? kInflxAtanC[threadIdx.x] : kInflxTanC[threadIdx.x - kInflxAtanTerms];
+  const double* const kc = epilogue_constants;  // published by the barrier below
+  constexpr bool kTable = OP == INFLX_OP_COMPLETE;
+#else
+  const double* const kc = nullptr;
+  constexpr bool kTable = false;
+#endif
 
   const unsigned tid = threadIdx.x;
   const unsigned lane = tid & (kWave - 1);
@@ -336,12 +370,12 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     }
   };
 
-#if INFLX_HAS_QUICK_POINT
-  // Hot loop: the point stage that divides by hoisted reciprocals.  A row in which some lane met an
-  // irregular quotient (NaN or infinite operands, overflow, a zero or denormal result...) is only noted here and
-  // evaluated after the loop with IEEE divisions -- by the whole wavefront, since the row is stored as a
-  // block -- so that the cold code costs the hot loop neither registers nor branches.
-  // Irregular quotients are usually structural: a numerator that is exactly zero in one grid column (sin 0, x1 = 0)
+  // Hot loop: the point stage that divides by hoisted reciprocals (models with enough such quotients) and the per-point
+  // operation that divides without special-case handling (inflx_op_complete_analysis_quick).  A row in which some lane
+  // met an irregular case (NaN or infinite operands, overflow, a zero or denormal quotient, a model value outside
+  // [2^-100, 2^100]...) is only noted here and evaluated after the loop with IEEE divisions -- by the whole wavefront,
+  // since the row is stored as a block -- so that the cold code costs the hot loop neither registers nor branches.
+  // Irregular cases are usually structural: a numerator that is exactly zero in one grid column (sin 0, x1 = 0)
   // fails in EVERY row of the wavefront that owns the column.  Such a wavefront would do all its rows twice
   // and hold its workgroup's slot 2.2 times as long as its neighbours (measured: +10 % on the whole D5 sweep at
   // 4096 columns); after two consecutive irregular rows it therefore stops trying and leaves the remaining rows
@@ -358,7 +392,13 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
     InflxModelValues mv;
     bool ok = true;
+#if INFLX_HAS_QUICK_POINT
     inflx_stage_point_quick(x0, x1, A, U, Rs[r], C, mv, ok);
+#else
+    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+#endif
+    double o[K];
+    ok = apply_op_quick<OP, kTable>(mv, o, a.accuracy, kc) && ok;
     // (lanes past N1 hold zeros for their column values and fail every acceptance test: they do not vote)
     if (__builtin_amdgcn_ballot_w64(!ok && in_range) != 0) {  // wave-uniform
       redo |= uint64_t(1) << r;
@@ -366,8 +406,6 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       continue;
     }
     streak = 0;
-    double o[K];
-    apply_op<OP>(mv, o, a.accuracy);
     emit(o, row);
   }
   if (nrows < 64) redo &= (uint64_t(1) << nrows) - 1;
@@ -377,22 +415,15 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     const uint64_t row = row0 + r;
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
     InflxModelValues mv;
+#if INFLX_HAS_QUICK_POINT
     inflx_stage_point_ieee(x0, x1, A, U, Rs[r], C, mv);
-    double o[K];
-    apply_op<OP>(mv, o, a.accuracy);
-    emit(o, row);
-  }
 #else
-  for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
-    const uint64_t row = row0 + r;
-    const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
-    InflxModelValues mv;
     inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+#endif
     double o[K];
-    apply_op<OP>(mv, o, a.accuracy);
+    apply_op<OP, kTable>(mv, o, a.accuracy, kc);
     emit(o, row);
   }
-#endif
   if constexpr (STATS) stat_flush(acc, a.stats);
 }
 
@@ -713,6 +744,32 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_basis_points(const 
   inflx_basis_point(a.points[2 * idx], a.points[2 * idx + 1], A, o);
 #pragma unroll
   for (int k = 0; k < 7; ++k) a.out[((uint64_t)blockIdx.y * a.n + idx) * 7 + k] = o[k];
+}
+
+// ops::* of src/anguelova.rs:99-171 applied to GIVEN model values -- no model evaluation: a.points holds n records
+// (V, v00, v10, v11, |dV|^2), a.out receives n records of 9 doubles: [0..5] complete_analysis, [6] consistency_only,
+// [7] consistency_rapidturn_only, [8] epsilon_v_only.  a.reserved = 0: complete_analysis exactly as the sweep kernels
+// evaluate it (divisions without special-case handling; the IEEE spelling for a wavefront in which some lane does not
+// qualify); 1: the IEEE spelling only.  This is how the per-point operations are pinned against the oracle on arbitrary
+// inputs -- specials, zeros, denormals, random bit patterns -- that no model produces on demand.
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_ops_on_values(const InflxTrajectoryArgs a) {
+  const uint64_t idx = (uint64_t)blockIdx.x * kThreads + threadIdx.x;
+  const bool live = idx < a.n;
+  InflxModelValues mv;
+  const double* rec = a.points + 5 * (live ? idx : 0);
+  mv.V = rec[0], mv.v00 = rec[1], mv.v10 = rec[2], mv.v11 = rec[3], mv.g = rec[4];
+  mv.b0 = mv.b1 = 0.0;
+  double o[6];
+  bool ok = false;
+  if (a.reserved == 0) ok = apply_op_quick<INFLX_OP_COMPLETE>(mv, o);
+  if (__builtin_amdgcn_ballot_w64(!ok && live) != 0) apply_op<INFLX_OP_COMPLETE>(mv, o);
+  if (!live) return;
+  double* dst = a.out + idx * 9;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dst[k] = o[k];
+  dst[6] = inflx_op_consistency_only(mv);
+  dst[7] = inflx_op_consistency_rapidturn_only(mv);
+  dst[8] = inflx_op_epsilon_v_only(mv);
 }
 
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }

@@ -9,6 +9,8 @@ Pieces:
                         per-model C file with the reference's ABI and builds it with gcc
                         using the reference's compiler flags.
   * ``cpu_oracle.py``   ctypes bindings for the two above (+ the basis-validation restatement).
+  * ``values_model.c``  a model artefact that returns table entries: the oracle's per-point operations on
+                        arbitrary (V, v00, v10, v11, |dV|^2) tuples (``ops_on_values``).
   * ``special.py``      mpmath / scipy.special stand-in for the reference's GSL special functions
                         (GSL is absent from this image: that row is **parity unpinned**).
 
@@ -18,5 +20,5 @@ half of the reference cannot be built in the authoring container (no rustc/cargo
 DESIGN.md "Oracle".
 """
 
-from .cpu_oracle import OP, OracleModel, build_sweep_library, grid_points, raw_long_double  # noqa: F401
+from .cpu_oracle import OP, OracleModel, build_sweep_library, grid_points, ops_on_values, raw_long_double  # noqa: F401
 from .model_c import emit_c_source, compile_c_model  # noqa: F401

@@ -146,6 +146,41 @@ class OracleModel:
         return self.grid_sweep(OP.COMPLETE, p, extent, N0, N1, threads=threads)
 
 
+# ---- the per-point operations on given model values ------------------------------------------------
+_values_model = None
+
+
+def ops_on_values(values, threads: int = 1) -> np.ndarray:
+    """(n,9): op_complete_analysis [0..5], op_consistency_only [6], op_consistency_rapidturn_only [7] and
+    op_epsilon_v_only [8] of ``sweep_oracle.c`` (src/anguelova.rs:99-163) for n given records
+    (V, v00, v10, v11, grad_norm_squared).  The records reach the oracle's unchanged sweep code through
+    ``values_model.c``, a model artefact whose functions read them from a table (x[0] = record number)."""
+    global _values_model
+    from .model_c import compile_c_model
+
+    values = np.ascontiguousarray(values, dtype=np.float64)
+    assert values.ndim == 2 and values.shape[1] == 5, values.shape
+    if _values_model is None:
+        with open(os.path.join(_HERE, "values_model.c")) as fh:
+            so = compile_c_model(fh.read(), flags=["-O2", "-shared", "-fPIC", "-std=c17", "-Wall", "-Werror"])
+        _values_model = (OracleModel(so), C.CDLL(so))
+    om, dll = _values_model
+    C.c_void_p.in_dll(dll, "inflx_values_table").value = values.ctypes.data
+    n = values.shape[0]
+    traj = np.zeros((n, 2))
+    traj[:, 0] = np.arange(n)
+    out = np.empty((n, 9))
+    p = np.zeros(1)
+    try:
+        out[:, :6] = om.trajectory_sweep(OP.COMPLETE, p, traj, threads=threads)
+        out[:, 6] = om.trajectory_sweep(OP.CONSISTENCY, p, traj, threads=threads)
+        out[:, 7] = om.trajectory_sweep(OP.RAPIDTURN, p, traj, threads=threads)
+        out[:, 8] = om.trajectory_sweep(OP.EPSILON_V, p, traj, threads=threads)
+    finally:
+        C.c_void_p.in_dll(dll, "inflx_values_table").value = None
+    return out
+
+
 # ---- basis validation (reference src/lib.rs:141-300) --------------------------------------------
 import math
 

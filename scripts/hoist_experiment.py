@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): tile-kernel time of the hoisted-reciprocal division against the default.
-usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, trust (-DINFLX_DIVH_TRUST: accept every quotient), w1 (1 wave/SIMD)"""
+usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, nohoist, trust (-DINFLX_DIVH_TRUST: accept every quotient),
+wN (N waves/SIMD: -DINFLX_MIN_WAVES=N), inner (grid away from the first row/column), DNAME=value (any -D switch of the kernel sources, e.g.
+DINFLX_HORNER_MODE=0, DINFLX_EXPERIMENT_IEEE_EPILOGUE=1, DINFLX_TAN_SHORTCUT_MAX=16)"""
 import os
 import sys
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -15,8 +16,14 @@ from workloads import example_models  # noqa: E402
 from inflatox_amd.compiler import Compiler  # noqa: E402
 
 n = int(os.environ.get("INFLX_EXPERIMENT_N", "4096"))
-stream = torch.cuda.current_stream().cuda_stream
-out = torch.empty((n, n, 6), dtype=torch.float64, device="cuda:0")
+# INFLX_EXPERIMENT_COMPILE_ONLY=1 (CPU container): build every variant into the in-tree cache, which travels to the GPU box
+compile_only = os.environ.get("INFLX_EXPERIMENT_COMPILE_ONLY") == "1"
+if not compile_only:
+    import torch
+
+    stream = torch.cuda.current_stream().cuda_stream
+    P = int(os.environ.get("INFLX_EXPERIMENT_P", "1"))  # parameter rows per call (BASELINE configs[2]: 32 for D5)
+    out = torch.empty((P, n, n, 6), dtype=torch.float64, device="cuda:0")
 cases = sys.argv[1:] or ["d5", "d5:hoist", "egno", "egno:hoist"]
 rounds = int(os.environ.get("INFLX_EXPERIMENT_ROUNDS", "1"))  # interleaved repetitions (A B A B ...): box-to-box and drift noise is +-3 %
 best = {}
@@ -26,8 +33,9 @@ for case in cases * rounds:
     spec = example_models.get(name)
     kw = dict(spec.compiler_kwargs)
     flags = list(Compiler.default_hipcc_flags)
-    if "w1" in fl:
-        flags.append("-DINFLX_MIN_WAVES=1")
+    for f in fl:
+        if len(f) == 2 and f[0] == "w" and f[1].isdigit():
+            flags.append(f"-DINFLX_MIN_WAVES={f[1]}")
     if "trust" in fl:
         flags.append("-DINFLX_DIVH_TRUST=1")
     for f in fl:
@@ -39,9 +47,16 @@ for case in cases * rounds:
         ext = (x0a + 0.1 * (x0b - x0a), x0b, x1a + 0.1 * (x1b - x1a), x1b)
     hoist = True if "hoist" in fl else (False if "nohoist" in fl else None)  # default: the compiler's automatic choice
     art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, hoist_reciprocals=hoist, **kw).compile()
+    if compile_only:
+        print("compiled", case, flush=True)
+        continue
     lib = _native.InflatoxDevLib(art.shared_object_path)
-    ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, out.data_ptr(), out.numel() * 8, ext, n, n, stream=stream, repeats=30) for _ in range(3))
+    rows = np.tile(np.asarray(spec.args, dtype=np.float64), (P, 1))
+    if name == "d5" and P > 1:
+        rows[:, 6] = np.linspace(2.5e-4, 1e-3, P)  # a1, as in bench.py
+    reps = max(2, 30 // P)
+    ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, ext, n, n, stream=stream, repeats=reps) for _ in range(3))
     best[case] = min(ms, best.get(case, 1e9))
-    print(f"{case:36s}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
+    print(f"{case:36s}: {ms:7.3f} ms  {P * n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
 for case, ms in best.items():
-    print(f"BEST {case:36s}: {ms:7.3f} ms  {n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
+    print(f"BEST {case:36s}: {ms:7.3f} ms  {P * n * n / ms / 1e6:7.2f} Gpts/s", flush=True)
