@@ -85,8 +85,17 @@ typedef double inflx_d2 __attribute__((ext_vector_type(2)));
 // (non-const on purpose: a const namespace-scope object would get internal linkage and vanish from
 // the code object's dynamic symbol table, where hipModuleGetGlobal looks it up)
 #define INFLX_EXPORT extern "C" __device__ __attribute__((used, visibility("default")))
-INFLX_EXPORT uint16_t VERSION[3] = {5, 0, 0};
-INFLX_EXPORT uint32_t DIM = INFLX_DIM;
+// (the two overrides exist for the negative ABI tests only: an artefact of another ABI version must be refused by
+// inflx_open like InflatoxDylib::open refuses it, src/dylib.rs:92-104; an artefact that says it has three fields must be
+// refused by the sweeps like Hesse2D::new refuses it, src/hesse_bindings.rs:203)
+#ifndef INFLX_ABI_VERSION_MAJOR
+#define INFLX_ABI_VERSION_MAJOR 5
+#endif
+#ifndef INFLX_EXPORTED_DIM
+#define INFLX_EXPORTED_DIM INFLX_DIM
+#endif
+INFLX_EXPORT uint16_t VERSION[3] = {INFLX_ABI_VERSION_MAJOR, 0, 0};
+INFLX_EXPORT uint32_t DIM = INFLX_EXPORTED_DIM;
 INFLX_EXPORT uint32_t N_PARAMETERS = INFLX_N_PARAMETERS;
 INFLX_EXPORT char MODEL_NAME[] = INFLX_MODEL_NAME;
 #ifndef INFLX_USE_GSL

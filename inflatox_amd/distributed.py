@@ -70,16 +70,18 @@ class ShardedSweep:
         self.world = world
         self.group = process_group
 
-    def run(self, args2d, N0: int, gather: bool = False):
+    def run(self, args2d, N0: int, gather: bool = False, force_collective: bool = False):
         """Returns ``(plan, local_block)`` or, with ``gather``, ``(plan, full)`` where ``full`` has the
-        shape (P, N0, N1, K) on every rank."""
+        shape (P, N0, N1, K) on every rank.  A world of one rank needs no exchange and returns its block as it is;
+        ``force_collective`` sends it through the all-gather all the same (how the RCCL code path is exercised on a
+        one-GPU box: one rank, backend "nccl")."""
         import torch
 
         args2d = np.atleast_2d(np.asarray(args2d, dtype=np.float64))
         P = args2d.shape[0]
         plan = plan_shard(P, N0, self.world, self.rank)
         local = self.compute(args2d[plan.p_begin : plan.p_begin + plan.p_count], plan.row_begin, plan.row_count)
-        if not gather or self.world == 1:
+        if not gather or (self.world == 1 and not force_collective):
             return plan, local
         import torch.distributed as dist
 

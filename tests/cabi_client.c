@@ -2,7 +2,9 @@
  * What a Rust/C maintainer of the reference would write: open an artefact, call the reference-shaped entry
  * points, read the error text on failure.  No Python, no torch in this process.
  *   usage: cabi_client ARTEFACT N0 N1 x0a x0b x1a x1b OUT.bin p0 [p1 ...]
- * writes N0*N1*6 doubles (complete_analysis) followed by N0*N1 doubles (consistency_only) to OUT.bin. */
+ * writes N0*N1*6 doubles (complete_analysis) followed by N0*N1 doubles (consistency_only) to OUT.bin.
+ * Exit codes the tests look at: 3 = inflx_open failed (status in the message), 4 = the artefact does not have two fields /
+ * the given number of parameters and inflx_complete_analysis refused it with INFLX_ERR_SHAPE (anything else: 9). */
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -33,7 +35,11 @@ int main(int argc, char** argv) {
   }
   if (inflx_n_fields(model) != 2 || inflx_n_parameters(model) != n_p) {
     fprintf(stderr, "model %s: %u fields, %u parameters (got %zu)\n", inflx_model_name(model), inflx_n_fields(model), inflx_n_parameters(model), n_p);
-    return 4;
+    /* the sweep itself must refuse such an artefact: Hesse2D::new asserts n_fields == 2 (src/hesse_bindings.rs:203) */
+    double probe[6];
+    rc = inflx_complete_analysis(model, p, inflx_n_parameters(model), probe, start_stop, 1, 1, 0, 0);
+    fprintf(stderr, "inflx_complete_analysis on it: status %d: %s\n", rc, inflx_last_error());
+    return rc == INFLX_ERR_SHAPE ? 4 : 9;
   }
   /* a wrong parameter count must be refused with the shape status, and leave the handle usable */
   double* six = calloc(n0 * n1 * 6, sizeof(double));

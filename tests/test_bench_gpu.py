@@ -36,6 +36,7 @@ def test_single_gpu_line():
     assert "workload" in line["config"] and "model" not in line["config"]
     assert roof["per_rank"][0]["rank"] == 0 and abs(roof["per_rank"][0]["kernel_ms"] - roof["kernel_ms"]) < 1e-9
     assert line["rccl_ranks"] == 0 and line["ranks"] == 1
+    assert line["config"]["parameter_rows_per_gpu"] == 1 and line["config"]["baseline_config"] == "configs[1]"
     # BASELINE configs[2] and [3] and the PCIe-inclusive front-end call ride on the same line (never part of `value`)
     sec = {rec["workload"].split(",")[0]: rec for rec in line["secondary"]}
     assert all("error" not in rec for rec in line["secondary"]), line["secondary"]
@@ -58,7 +59,9 @@ def test_two_rank_rehearsal(form):
     before anything has touched the GPU) and under torch.distributed.run."""
     env = dict(os.environ, INFLX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
-    tail = ["bench.py", "--gpus", "2", "--grid", "2048", "--steps", "5", "--warmup", "2"]
+    rows = 3 if form == "plain" else None  # default at N > 1: 64 rows per GPU (BASELINE configs[4]); 2048^2 x 64 = 12.9 GB per rank
+    tail = ["bench.py", "--gpus", "2", "--grid", "2048", "--steps", "5", "--warmup", "2"] + (["--rows-per-gpu", str(rows)] if rows else [])
+    rows = rows or 64
     if form == "plain":
         cmd = [sys.executable, *tail]
     else:
@@ -70,7 +73,9 @@ def test_two_rank_rehearsal(form):
     assert "secondary" not in line
     assert line["n_gpus"] == 2 and "cpu_baseline" not in line
     assert "REHEARSAL" in line["config"]["parallelism"]
-    # both ranks' rows are counted: value = 2 * points * steps / max-over-ranks time
-    assert abs(line["value"] - 2 * 2048 * 2048 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-9
-    # the summary of the two parameter rows was combined across ranks (epsilon_V is finite everywhere)
-    assert line["summary_sweep"]["non_nan"][1] == 2 * 2048 * 2048
+    # every rank's rows are counted: value = ranks * rows per rank * points * steps / max-over-ranks time
+    assert abs(line["value"] - 2 * rows * 2048 * 2048 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-9
+    assert line["config"]["parameter_rows_per_gpu"] == rows and line["config"]["parameter_rows_total"] == 2 * rows
+    assert "configs[4]" in line["config"]["baseline_config"] and "linspace(0.2, 2.0, 512)" in line["config"]["workload"]
+    # the summary of all parameter rows was combined across ranks (epsilon_V is finite everywhere)
+    assert line["summary_sweep"]["non_nan"][1] == 2 * rows * 2048 * 2048

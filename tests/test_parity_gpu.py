@@ -277,20 +277,95 @@ def test_full_size_sampled_against_oracle(name, n, gpu_lib):
 
 @pytest.mark.parametrize("name", MODELS)
 def test_flag_quantum_dif(name, gpu_lib):
-    """GeneralisedAL.flag_quantum_dif vs the oracle (ops::flag_quantum_diff, src/anguelova.rs:166-170,574-626)."""
-    from inflatox_amd.consistency_conditions import GeneralisedAL
-
+    """GeneralisedAL.flag_quantum_dif vs the oracle (ops::flag_quantum_diff, src/anguelova.rs:166-170,574-626).  The
+    result is one byte per point and must be EXACT, except where a component of the normalised gradient sits on the
+    threshold: a point may differ from the oracle only if one of the components the oracle computes there is within
+    the rounding distance of `accuracy` -- 64 ulps, or 64 times the amount by which the reference's own component moves
+    when the point moves by a few ulps (tolerance.basis_sensitivity), where that is larger."""
     spec, art, lib = devlib(name, gpu_lib)
     om, _ = oracle_model(name)
     al = generalised_al(art)
-    n0, n1 = 130, 333
+    n0, n1 = 96, 150
+    pts = oracle.grid_points(spec.extent, n0, n1)
+    basis_all = oracle.cpu_oracle.basis_on_points(om.path, spec.args, pts)
+    basis = basis_all[:, 3:5].reshape(n0, n1, 2)  # the C function `v`
     for accuracy in (1e-3, 0.5, 0.9):
         got = al.flag_quantum_dif(spec.args, *spec.extent, n0, n1, progress=False, accuracy=accuracy)
         assert got.dtype == np.bool_ and got.shape == (n0, n1)
         want = om.grid_sweep(OP.QDIF, spec.args, spec.extent, n0, n1, accuracy=accuracy)
-        # a gradient component within a few ulps of the threshold may flip; nothing else may
-        assert (got != want).mean() <= 0.002, (name, accuracy, int((got != want).sum()))
+        with np.errstate(invalid="ignore"):
+            assert np.array_equal(want, (basis[..., 0] <= accuracy) & (basis[..., 1] <= accuracy)), "oracle flag and oracle basis disagree"
+        differ = np.flatnonzero((got != want).reshape(-1))
+        assert differ.size <= 0.002 * got.size, (name, accuracy, differ.size)
+        if differ.size:
+            spread = tol.basis_sensitivity(name, spec.args, pts[differ], basis_all[differ])[:, 3:5]
+            slack = np.maximum(64 * np.spacing(accuracy), 64.0 * spread)
+            on_threshold = (np.abs(basis_all[differ, 3:5] - accuracy) <= slack).any(axis=-1)
+            assert on_threshold.all(), (name, accuracy, int((~on_threshold).sum()), "first stray point", pts[differ][~on_threshold][0], basis_all[differ][~on_threshold][0, 3:5])
     assert got.any() or not want.any()
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_gpu_is_as_close_to_the_50_digit_truth_as_the_reference(name, gpu_lib):
+    """Independent of every allowance of tests/tolerance.py: the goldens store, beside the reference's float64 model
+    values, the values of the SAME expressions in 50-digit arithmetic (`*_raw_mp`, tests/golden/make_golden.py).  The
+    GPU must be no farther from that truth than the reference itself is.  Both are samples of a rounding-error
+    distribution (at a single point either may be lucky), so the statement is made where it is well defined:
+
+      * the distribution of the relative error over the grid, per model value: the GPU's median and 90 % quantile are at
+        most 3x the reference's (floor 1e-10, the bar of north_star), and in the tail the GPU has, at every level X
+        from 3e-10 to 1, no more values with an error above X than the reference has above X/3 (x1.5);
+      * point by point, symmetrically: the points where the GPU is more than 4x farther from the truth than the
+        reference (floor 1e-10 |truth|) are not more numerous than the points where the reference is more than 4x
+        farther than the GPU, up to sampling noise;
+      * wherever truth and reference are finite the GPU is finite.
+    Measured on the host twin (same arithmetic, glibc instead of OCML): quantile ratios <= 1.6, maximum <= 3.5, the
+    two counts 1440 / 1145 of 15360 for EGNO 64x48 (its float64 evaluation is off by 5e-9 in the median), 0 / 0 for
+    the well-conditioned models."""
+    spec, art, lib = devlib(name, gpu_lib)
+    g = golden(name)
+    report = []
+    for tag in ("g16", "g64"):
+        n0, n1 = (int(v) for v in g[f"{tag}_shape"])
+        truth, ref = g[f"{tag}_raw_mp"], g[f"{tag}_raw"]
+        got = lib.sweep_host(gpu_lib.OP_RAW, g["args"], g[f"{tag}_extent"], n0, n1)
+        firm = np.isfinite(truth) & np.isfinite(ref)
+        assert np.isfinite(got[firm]).all(), f"{name}/{tag}: GPU not finite where truth and reference are"
+        with np.errstate(all="ignore"):
+            e_ref, e_got = np.abs(ref - truth), np.abs(got - truth)
+            r_ref, r_got = e_ref / np.abs(truth), e_got / np.abs(truth)
+            floor = 1e-10 * np.abs(truth)
+            # away from the singular lines of a model (D5: theta = k pi/2, where the truth is 0 or ~1e-23 and what the
+            # reference returns is a cancellation artefact of no relation to it): the reference itself within 1e-3
+            ok = firm & (truth != 0) & (r_ref <= 1e-3)
+        assert ok.mean() >= 0.70, f"{name}/{tag}: only {100 * ok.mean():.1f} % of the values are compared"
+        exact_zero = firm & (truth == 0) & (ref == 0)  # e.g. v10 of the hyperbolic model
+        assert (got[exact_zero] == 0).all(), f"{name}/{tag}: GPU nonzero where truth and reference are exactly zero"
+        with np.errstate(all="ignore"):
+            gpu_worse = int((ok & (e_got > 4 * np.maximum(e_ref, floor))).sum())
+            ref_worse = int((ok & (e_ref > 4 * np.maximum(e_got, floor))).sum())
+        assert gpu_worse <= 1.5 * ref_worse + 0.002 * ok.sum() + 3, f"{name}/{tag}: GPU > 4x farther from the truth at {gpu_worse} points, reference at {ref_worse}"
+        for k, what in enumerate(("V", "v00", "v10", "v11", "g")):
+            m = ok[..., k]
+            if not m.any():
+                continue
+            q_ref = np.percentile(r_ref[..., k][m], (50, 90, 99, 100))
+            q_got = np.percentile(r_got[..., k][m], (50, 90, 99, 100))
+            # the bulk of the distribution: median and 90 % quantile
+            assert (q_got[:2] <= 3.0 * np.maximum(q_ref[:2], 1e-10)).all(), f"{name}/{tag}/{what}: relative error quantiles 50/90 % gpu {q_got[:2]} reference {q_ref[:2]}"
+            # its tail, where a quantile is a noisy thing (next to a zero crossing of v10 the relative error rises by
+            # three decades between the 90 % and the 99 % quantile): exceedance counts instead -- at every level X the
+            # GPU has no more values with a relative error above X than the reference has above X/3 (x1.5, + noise)
+            for level in 10.0 ** np.arange(-9.5, 0.01, 0.5):
+                n_got, n_ref = int((r_got[..., k][m] > level).sum()), int((r_ref[..., k][m] > level / 3).sum())
+                assert n_got <= 1.5 * n_ref + 0.002 * m.sum() + 3, f"{name}/{tag}/{what}: {n_got} values with relative error > {level:.1e} on the GPU, {n_ref} > {level / 3:.1e} in the reference"
+            report.append((tag, what, q_ref, q_got))
+        report.append((tag, "counts", gpu_worse, ref_worse))
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, f"truth_report_{name}.txt"), "w") as fh:
+        for rec in report:
+            fh.write(" ".join(str(v) for v in rec) + "\n")
 
 
 def test_array_helpers(gpu_lib):
@@ -911,3 +986,114 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     bogus.write_bytes(b"not a code object")
     proc = subprocess.run([str(exe), str(bogus), "4", "4", "0", "1", "0", "1", str(out), "1.0"], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 3 and "inflx_open failed (1)" in proc.stderr
+
+
+def test_artefacts_of_another_abi_version_or_dimension_are_refused(gpu_lib, tmp_path):
+    """Negative ABI tests.  InflatoxDylib::open refuses an artefact whose VERSION differs in major.minor from the
+    library's 5.0 (src/dylib.rs:92-104, src/inflatox_version.rs:48-53) -> LibInflxRsErr::Version -> SystemError
+    (src/err.rs:70); Hesse2D::new refuses a model that does not have two fields (src/hesse_bindings.rs:203).  The
+    hyperbolic model is built twice with compile-time overrides of the exported globals (VERSION = {4,0,0}; DIM = 3) and
+    pushed through inflx_open / inflx_complete_analysis from Python and from the plain C client."""
+    import subprocess
+
+    from inflatox_amd import _native
+    from inflatox_amd.compiler import Compiler
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    import workloads
+
+    spec = workloads.example_models.get("hyperbolic")
+    model = workloads.model_for("hyperbolic")
+    flags = list(Compiler.default_hipcc_flags)
+    old = Compiler(model, silent=True, compiler_flags=flags + ["-DINFLX_ABI_VERSION_MAJOR=4"], **spec.compiler_kwargs).compile()
+    wide = Compiler(model, silent=True, compiler_flags=flags + ["-DINFLX_EXPORTED_DIM=3"], **spec.compiler_kwargs).compile()
+
+    # Python: wrong version -> INFLX_ERR_VERSION -> SystemError, at open (also through the front-end's constructor)
+    with pytest.raises(SystemError, match=r"ABI v4\.0\.0"):
+        gpu_lib.InflatoxDevLib(old.shared_object_path)
+    with pytest.raises(SystemError, match="ABI"):
+        GeneralisedAL(old)
+    # three fields: the artefact opens (the reference's open does not look at DIM either) and every sweep refuses it
+    lib3 = gpu_lib.InflatoxDevLib(wide.shared_object_path)
+    assert lib3.n_fields == 3
+    out = np.zeros((4, 4, 6))
+    with pytest.raises(gpu_lib.InflatoxShapeError, match="2-field model"):
+        lib3.complete_analysis(spec.args, out, np.array(spec.extent).reshape(2, 2))
+    assert not isinstance(gpu_lib.InflatoxShapeError("x"), (SystemError, IOError, ValueError))  # a plain Exception, err.rs:71
+    with pytest.raises(gpu_lib.InflatoxShapeError):
+        lib3.sweep_on_trajectory(gpu_lib.OP_COMPLETE, spec.args, np.zeros((3, 2)))
+    assert (out == 0).all()
+
+    # the same two artefacts through the C ABI alone
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "cabi_client"
+    libdir = os.path.dirname(_native.LIB_PATH)
+    subprocess.run(
+        ["gcc", "-O1", "-std=c11", "-Wall", "-Werror", f"-I{os.path.join(root, 'include')}", os.path.join(root, "tests", "cabi_client.c"), f"-L{libdir}", "-linflx_hip", f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib", "-o", str(exe)],
+        check=True,
+    )
+    tail = ["4", "4", *[repr(float(v)) for v in spec.extent], str(tmp_path / "out.bin"), *[repr(float(v)) for v in spec.args]]
+    proc = subprocess.run([str(exe), old.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 3 and f"inflx_open failed ({_native.ERR_VERSION})" in proc.stderr, (proc.returncode, proc.stderr)
+    proc = subprocess.run([str(exe), wide.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 4 and f"status {_native.ERR_SHAPE}" in proc.stderr, (proc.returncode, proc.stderr)
+
+
+def test_broadcast_views_and_device_resident_result(gpu_lib):
+    """Opt-in extensions of the front-end call (consistency_conditions.GeneralisedAL.complete_analysis):
+    ``broadcast_views=True`` returns, for a model that ignores one field, six read-only stride-0 views of ONE evaluated
+    line -- equal, element for element, to the arrays of the default call -- and ``complete_analysis_device`` leaves the
+    result on the GPU as six torch views (DLPack / __cuda_array_interface__).  Defaults stay the reference's: writable
+    stride-48 views of one (N0, N1, 6) host array (consistency_conditions.py:301-308)."""
+    import time
+
+    import torch
+    from test_models_extra import setup
+
+    from inflatox_amd import Compiler
+
+    # row-only: the README hyperbolic model
+    spec, art, _ = devlib("hyperbolic", gpu_lib)
+    al = generalised_al(art)
+    for n0, n1 in ((257, 130), (64, 1), (1, 77)):
+        full = al.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False)
+        lean = al.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False, broadcast_views=True)
+        assert len(lean) == 6
+        for f, b in zip(full, lean):
+            assert f.flags.writeable and f.strides == (n1 * 48, 48)
+            assert b.shape == (n0, n1) and not b.flags.writeable and (n1 == 1 or b.strides[1] == 0)
+            assert np.array_equal(f, b, equal_nan=True)
+    # the headline grid: 393 kB over PCIe instead of 3.2 GB
+    n = 8192
+    al.complete_analysis(spec.args, *spec.extent, n, n, progress=False, broadcast_views=True)
+    t0 = time.perf_counter()
+    lean = al.complete_analysis(spec.args, *spec.extent, n, n, progress=False, broadcast_views=True)
+    ms = (time.perf_counter() - t0) * 1e3
+    assert ms < 2.0, f"broadcast_views call took {ms:.2f} ms"
+    dev = al.complete_analysis_device(spec.args, *spec.extent, n, n)
+    torch.cuda.synchronize()
+    assert all(t.is_cuda and t.shape == (n, n) and t.stride() == (n * 6, 6) and t.dtype == torch.float64 for t in dev)
+    assert hasattr(dev[0], "__dlpack__") and dev[0].__cuda_array_interface__["shape"] == (n, n)
+    for k in (1, 4):  # eps_V and delta against the broadcast line (every row is constant along x1)
+        col = dev[k][:, :1]
+        assert bool(((dev[k] == col) | (torch.isnan(dev[k]) & torch.isnan(col))).all())
+        assert np.array_equal(col[:, 0].cpu().numpy(), np.ascontiguousarray(lean[k][:, 0]), equal_nan=True)
+    del dev
+    torch.cuda.empty_cache()
+    # column-only: the synthetic mirror image (tests/test_models_extra.py)
+    model, args, ext, om, comp, hdr, symdict = setup("column_only")
+    al2 = generalised_al(Compiler(model, silent=True).compile())
+    n0, n1 = 93, 210
+    full = al2.complete_analysis(args, *ext, n0, n1, progress=False)
+    lean = al2.complete_analysis(args, *ext, n0, n1, progress=False, broadcast_views=True)
+    for f, b in zip(full, lean):
+        assert b.shape == (n0, n1) and b.strides[0] == 0 and not b.flags.writeable and np.array_equal(f, b, equal_nan=True)
+    # a model that depends on both fields takes the ordinary path whatever the flag says
+    spec_d, art_d, _ = devlib("doc", gpu_lib)
+    al3 = generalised_al(art_d)
+    a = al3.complete_analysis(spec_d.args, *spec_d.extent, 40, 36, progress=False)
+    b = al3.complete_analysis(spec_d.args, *spec_d.extent, 40, 36, progress=False, broadcast_views=True)
+    assert all(y.flags.writeable and np.array_equal(x, y, equal_nan=True) for x, y in zip(a, b))
+    # the device-resident result of a tile-path model equals the host result bit for bit
+    dev = al3.complete_analysis_device(spec_d.args, *spec_d.extent, 40, 36)
+    assert all(np.array_equal(t.cpu().numpy(), x, equal_nan=True) for t, x in zip(dev, a))
