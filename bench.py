@@ -42,7 +42,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full rate (78.6 TFLOP/s = 2 flop x this)
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
-PROFILE_ROUNDS = ("02", "01")  # profiles/rNN_traffic.json, rNN_valu.json: newest first
+PROFILE_ROUNDS = ("03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json: newest first
 
 
 def host_threads() -> int:
@@ -132,7 +132,7 @@ def self_launch(opt) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def secondary_workloads(_native, workloads, torch, np, device, stream):
+def secondary_workloads(_native, workloads, torch, np, device, stream, only=None):
     """BASELINE configs[2] and [3] on this GPU, kernel time by HIP events on the launch stream (no part of `value`).
     These are FP64-VALU-bound: the roofline that prices them is the VALU issue rate, from
     the SQ instruction counters on record for exactly this code object; the HBM fraction is given beside it."""
@@ -143,6 +143,8 @@ def secondary_workloads(_native, workloads, torch, np, device, stream):
         ("doc", 4096, 1, 30, "documentation model (reference tests/test_doc.py), 4096x4096 field grid"),
     ]
     for name, n, P, repeats, text in cases:
+        if only is not None and name != only:  # scripts/secondary_probe.py: one workload per profiler run
+            continue
         try:
             spec, art = workloads.artifact_for(name)
             lib = _native.InflatoxDevLib(art.shared_object_path, device=device)

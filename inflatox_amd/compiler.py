@@ -276,14 +276,18 @@ class Compiler:
       stored values are the IEEE program's bit for bit).  4.8 fma-equivalents of issue time per quotient
       against 13.0, and nothing but the three operations when the numerator is a product of earlier-stage
       values (validity then follows from per-row / per-column / per-sweep range flags).  ``None`` turns it on
-      when at least ``HOIST_MIN_QUOTIENTS`` divisions of the five sweep values qualify (D5: 29 of 53 divisions,
+      when the quick point stage saves at least ``HOIST_MIN_GAIN`` instructions per point (D5: 29 of 53 divisions hoisted,
       0.592 -> 0.519 ms per 4096^2 sweep on MI355X); ``True`` / ``False`` force it.
-
-    * ``tan_shortcut`` (default 0 = off; ``None`` reads the environment variable ``INFLX_TAN_SHORTCUT``): the epilogue's
+    * ``share_reciprocals`` (default False): in the quick point stage, quotients with the same PER-POINT denominator (D5
+      divides four times by ``r_44*p_5``) share one refined reciprocal (csrc/inflx_device_math.h).  Exact, and 32 fewer
+      instructions per point for D5 -- but the additional comparisons and live values cost as much again (SGPR spills,
+      three wavefronts per SIMD no longer fit): 13.9 -> 14.8 ms for D5 4096^2 x 32, hence off (profiles/r03_experiments.txt).
+    * ``tan_shortcut`` (default 16; 0 = off; ``None`` reads the environment variable ``INFLX_TAN_SHORTCUT``, else the default): the epilogue's
       ``tan(atan(t))``, t = |v10/v00| (src/anguelova.rs:128,132), is taken as ``t`` itself wherever ``t <= tan_shortcut``.
-      The reference's two libm calls return t(1 + e) with |e| <~ (t + 1/t)*2^-53, so the results differ from the default
-      mode's by at most ~(tan_shortcut + 1)*2^-53 relative on ``tan(delta)`` -- far inside the 1e-10 bar, and closer to the
-      exact value than the reference itself -- but they are no longer OCML's tan of OCML's atan bit for bit; a wavefront
+      The reference's two libm calls return t(1 + e) with |e| <~ (t + 1/t)*2^-53, so the results differ from those of
+      ``tan_shortcut=0`` by at most ~(tan_shortcut + 1)*2^-53 relative on ``tan(delta)`` -- far inside the 1e-10 bar, and closer to the
+      exact value than the reference itself -- but they are not OCML's tan of OCML's atan bit for bit (``tan_shortcut=0``
+      gives that); a wavefront
       all of whose points qualify skips the ~55 instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
@@ -292,9 +296,21 @@ class Compiler:
     print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
     """
 
-    #: `hoist_reciprocals=None` turns the hoisted-reciprocal division on when the five sweep values contain at least
-    #: this many per-point quotients by a denominator of an earlier stage
-    HOIST_MIN_QUOTIENTS = 16  # measured at 4096^2: D5 (29) 0.592 -> 0.519 ms; EGNO (12) 0.457 -> 0.465 ms; doc (1) 0.263 -> 0.269 ms
+    #: `hoist_reciprocals=None` turns the quick point stage (hoisted and shared reciprocals) on when it removes at least
+    #: this many VALU instructions per grid point from the five sweep values (quick_point_gain)
+    #: (D5: 224, on: 0.592 -> 0.519 ms per 4096^2 sweep in round 2.  EGNO: 88, off: with it 0.409 -> 0.422 ms in round 3 --
+    #: its quick point stage needs 20 spilled registers to keep three wavefronts per SIMD, or falls back to two.)
+    HOIST_MIN_GAIN = 100
+    #: default of ``tan_shortcut`` (0 = off): profiles/r03_experiments.txt, the whole GPU parity suite is green with it
+    DEFAULT_TAN_SHORTCUT = 16
+
+    @staticmethod
+    def quick_point_gain(info) -> int:
+        """VALU instructions per grid point the quick point stage saves (estimate from the generated header)."""
+        hoisted, pure = info.get("hoisted_quotients", 0), info.get("pure_quotients", 0)
+        shared, groups = info.get("shared_quotients", 0), info.get("shared_reciprocals", 0)
+        return 8 * pure + 7 * (hoisted - pure) + 7 * shared - 6 * groups
+
     #: three wavefronts per SIMD are kept when the tile kernel of complete_analysis needs at most this much scratch per lane
     MAX_SCRATCH_FOR_THREE_WAVES = 128
     c_prefix = "inflx_auto_"
@@ -335,6 +351,7 @@ class Compiler:
         regroup: bool = False,
         hoist_reciprocals: bool | None = None,
         tan_shortcut: float | None = None,
+        share_reciprocals: bool = False,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -350,8 +367,9 @@ class Compiler:
         self.staged = staged
         self.regroup = regroup
         self.hoist_reciprocals = hoist_reciprocals
+        self.share_reciprocals = bool(share_reciprocals)
         if tan_shortcut is None:
-            tan_shortcut = float(os.environ.get("INFLX_TAN_SHORTCUT", "0") or 0)
+            tan_shortcut = float(os.environ.get("INFLX_TAN_SHORTCUT", "") or self.DEFAULT_TAN_SHORTCUT)
         if tan_shortcut < 0 or tan_shortcut != int(tan_shortcut) or tan_shortcut >= 2**17:
             raise ValueError("tan_shortcut must be a whole number in [0, 2^17): the largest |v10/v00| for which tan(atan(t)) is taken as t")
         self.tan_shortcut = int(tan_shortcut)
@@ -450,13 +468,16 @@ class Compiler:
                 cse_vector=cse_vector,
                 regroup=self.regroup,
                 hoist_reciprocals=hoist,
+                share_point_reciprocals=self.share_reciprocals,
             )
 
         if self.hoist_reciprocals is None:
             # automatic: the second copy of the point stage and the bookkeeping around it only pay when enough
-            # IEEE divisions leave the per-point stage (D5: 29 of 53; EGNO: 12 of 30; the documentation model: 1 of 16)
+            # instructions leave the per-point stage: an IEEE division is 11, a quotient by a hoisted reciprocal 3 (+1
+            # comparison unless its numerator is made of earlier-stage values), one by a shared per-point reciprocal 3 + 1
+            # and the 5 + 1 of the reciprocal once per group
             text, info = emit(self.staged)
-            if info["hoisted_quotients"] < self.HOIST_MIN_QUOTIENTS:
+            if self.quick_point_gain(info) < self.HOIST_MIN_GAIN:
                 text, info = emit(False)
         else:
             text, info = emit(self.hoist_reciprocals)

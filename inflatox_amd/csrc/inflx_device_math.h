@@ -103,6 +103,34 @@ INFLX_FN double inflx_div_by_hoisted(double a, double b, double y, bool& ok) {
   return q;
 }
 
+// ---- quotients of the point stage that share a PER-POINT denominator ---------------------------------------
+// (D5 divides four times by r_44*p_5 at every grid point.)  The compiler's IEEE division is: two v_div_scale, v_rcp_f64
+// and two Newton steps on the reciprocal (5 instructions), then q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) (v_div_fmas
+// with nothing scaled), v_div_fixup.  For operands in mid range the scaling and the fix-up change nothing, so the
+// quotient is exactly what the eight arithmetic instructions deliver (inflx_ops.h has the argument in full) -- and the
+// five of the reciprocal depend on the denominator alone: quotients with the same denominator share them and cost
+// three instructions and one comparison each instead of eleven.  "Mid range" is tested, not assumed: the denominator's
+// exponent field once per reciprocal (2^-500 <= |b| < 2^501), |q| >= 2^-400 per quotient (a NaN, an infinity, an
+// overflow or a zero anywhere fail one of the two); a point that fails clears `ok` and the tile kernel evaluates its
+// grid row again with the compiler's divisions, so the stored values are the IEEE program's always.
+#ifndef INFLX_HOST_TWIN
+INFLX_FN double inflx_shared_reciprocal(double b, bool& ok) {
+  const double y0 = __builtin_amdgcn_rcp(b);
+  const double y1 = __builtin_fma(y0, __builtin_fma(-b, y0, 1.0), y0);
+  ok = ok && ((((unsigned)__double2hiint(b) >> 20) & 0x7ffu) - (1023u - 500u) <= 1000u);
+  return __builtin_fma(y1, __builtin_fma(-b, y1, 1.0), y1);
+}
+INFLX_FN double inflx_div_by_shared(double a, double b, double y, bool& ok) {
+  const double q0 = a * y;
+  const double q = __builtin_fma(__builtin_fma(-b, q0, a), y, q0);
+  ok = ok && (__builtin_fabs(q) >= 0x1p-400);
+  return q;
+}
+#else
+INFLX_FN double inflx_shared_reciprocal(double, bool&) { return 0.0; }
+INFLX_FN double inflx_div_by_shared(double a, double b, double, bool&) { return a / b; }
+#endif
+
 // reciprocal hyperbolic / trigonometric functions sympy may emit without a C99 spelling
 INFLX_FN double inflx_coth(double x) { return 1.0 / tanh(x); }
 INFLX_FN double inflx_sech(double x) { return 1.0 / cosh(x); }

@@ -520,7 +520,8 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
   if (gx > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch (%zu column tiles)", gx);
   if (row_count > 0xffffffffULL) return fail(INFLX_ERR_SHAPE, "at most 2^32 grid rows per call (got %zu)", row_count);
   hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
-  const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nr = std::max<size_t>(m->info.n_row, 1), nc = std::max<size_t>(m->info.n_col, 1);
+  const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nc = std::max<size_t>(m->info.n_col, 1);
+  const size_t nr = (std::max<size_t>(m->info.n_row, 1) + 1) & ~size_t(1);  // even stride of a row's values (kNRs of the kernels)
   const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
   const size_t slab_max = std::min(rows_per_launch, row_count);
   const size_t per_p = nu + slab_max * nr + nc * N1;  // doubles per parameter row

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 14u
+#define INFLX_KERNEL_ABI 15u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -56,7 +56,7 @@ struct InflxSweepArgs {
   // and inflx_sweep_colstream copies image z into every grid row: out unit ((z*row_count + row)*stream_units + u)
   uint64_t stream_units;  // 16-byte units per output row
   // tile kernels (some value depends on x[1]): row_table holds the stage tables inflx_stage_tables wrote for this launch,
-  //   U[P][max(NU,1)] | R[P][slab_rows][max(NR,1)] | C[P][max(NC,1)][N1]   (doubles),
+  //   U[P][max(NU,1)] | R[P][slab_rows][NRs] | C[P][max(NC,1)][N1]   (doubles; NRs = max(NR,1) rounded up to even),
   // the slab being grid rows [stream_row0, stream_row0 + stream_units) relative to row_begin (stream_units = slab_rows here)
 };
 

@@ -75,6 +75,9 @@ constexpr int kTileRows = INFLX_TILE_ROWS;
 constexpr int kRowsPerBlock = INFLX_ROWS_PER_BLOCK;
 constexpr int kNU = INFLX_NU > 0 ? INFLX_NU : 1;
 constexpr int kNR = INFLX_NR > 0 ? INFLX_NR : 1;
+// stride of a row's R values in the stage table and in LDS: even, so that every pair of values is one aligned 16-byte
+// LDS read (an odd stride costs ds_read2_b64 pairs at twice the LDS cycles of ds_read_b128; D5 has 69 values, EGNO 82)
+constexpr int kNRs = (kNR + 1) & ~1;
 constexpr int kNC = INFLX_NC > 0 ? INFLX_NC : 1;
 constexpr int kNP = INFLX_N_PARAMETERS > 0 ? INFLX_N_PARAMETERS : 1;
 
@@ -247,7 +250,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   static_assert(!STATS || OP == INFLX_OP_COMPLETE, "the summary is defined for the six outputs of complete_analysis");
   StatAcc acc;
   if constexpr (STATS) stat_init(acc);
-  __shared__ double Rs[kTileRows][kNR];
+  __shared__ __attribute__((aligned(16))) double Rs[kTileRows][kNRs];
   __shared__ __attribute__((aligned(16))) double tbuf[kThreads / kWave][kWave * 6];
 #if INFLX_EPILOGUE_CONSTANTS_IN_LDS
   // the 34 polynomial coefficients of the epilogue's atan / tan: read back as LDS broadcasts straight into the
@@ -275,8 +278,8 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   // 6 % of the D5 sweep and 8 % of the angular one, measured by skipping it).
   const uint64_t slab_rows = a.stream_units;  // grid rows covered by this launch's tables, first one = stream_row0
   const double* __restrict__ utab = a.row_table + (uint64_t)p * kNU;
-  const double* __restrict__ rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNR;
-  const double* __restrict__ ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNR) + (uint64_t)p * kNC * a.N1;
+  const double* __restrict__ rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNRs;
+  const double* __restrict__ ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNRs) + (uint64_t)p * kNC * a.N1;
   const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
   const uint64_t j = col0 + tid;
   const double x1 = inflx_coord(j, a.dx1, a.x1a);
@@ -286,7 +289,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
 #ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE  // (A/B experiment only: the round-1 prologue, every workgroup evaluates its own stage values)
 #if INFLX_U_IN_LDS
-  __shared__ double U[kNU];
+  __shared__ __attribute__((aligned(16))) double U[kNU];
   if (tid == 0) inflx_stage_uniform(A, U);
   __syncthreads();
 #else
@@ -302,7 +305,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #if INFLX_U_IN_LDS
   // wave-uniform values live in LDS: every use is a broadcast read and costs no long-lived VGPRs
   // (a uniform f64 cannot be an operand from SGPRs more than once per instruction, and there are up to hundreds)
-  __shared__ double U[kNU];
+  __shared__ __attribute__((aligned(16))) double U[kNU];
   for (unsigned k = tid; k < (unsigned)kNU; k += kThreads) U[k] = utab[k];
 #else
   double U[kNU];
@@ -313,9 +316,9 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #pragma unroll
   for (int k = 0; k < kNC; ++k) C[k] = j < a.N1 ? ctab[(uint64_t)k * a.N1 + j] : 0.0;
   {
-    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * kTileRows * kNR;
+    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * kTileRows * kNRs;
     double* dst = &Rs[0][0];
-    for (unsigned i = tid; i < (unsigned)(nrows * kNR); i += kThreads) dst[i] = src[i];
+    for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
   }
   __syncthreads();
 #endif
@@ -680,7 +683,7 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
 // stage tables of the tile kernels: U per parameter row, R per grid row, C per grid column
 // ================================================================================================
 // grid: x = 256-thread blocks over max(slab rows, N1), y = parameter row.  Table layout (doubles) behind a.row_table:
-//   U[P][kNU]  |  R[P][slab_rows][kNR]  |  C[P][kNC][N1]
+//   U[P][kNU]  |  R[P][slab_rows][kNRs]  |  C[P][kNC][N1]      (kNRs = kNR rounded up to even)
 // (R row-major so that a tile's 32 rows are one contiguous block, C value-major so that the threads of a tile read
 // every value coalesced).  The slab is rows [stream_row0, stream_row0 + stream_units) relative to row_begin.
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const InflxSweepArgs a) {
@@ -689,12 +692,12 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const 
   const uint64_t idx = (uint64_t)blockIdx.x * kThreads + tid;
   const uint64_t slab_rows = a.stream_units;
   double* utab = a.row_table + (uint64_t)p * kNU;
-  double* rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNR;
-  double* ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNR) + (uint64_t)p * kNC * a.N1;
+  double* rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNRs;
+  double* ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNRs) + (uint64_t)p * kNC * a.N1;
   double A[kNP];
   load_params(a.params, p, A);
 #if INFLX_U_IN_LDS
-  __shared__ double U[kNU];
+  __shared__ __attribute__((aligned(16))) double U[kNU];
   if (tid == 0) inflx_stage_uniform(A, U);
   __syncthreads();
   if (blockIdx.x == 0)
@@ -711,7 +714,7 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const 
 #endif
   if (idx < slab_rows) {
     const double x0 = inflx_coord(a.row_begin + a.stream_row0 + idx, a.dx0, a.x0a);
-    inflx_stage_row(x0, A, U, rtab + idx * kNR);
+    inflx_stage_row(x0, A, U, rtab + idx * kNRs);
   }
   if (idx < a.N1) {
     const double x1 = inflx_coord(idx, a.dx1, a.x1a);

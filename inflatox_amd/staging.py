@@ -226,8 +226,16 @@ class HIPInflatoxPrinter(C99CodePrinter):
             if recip is not None:
                 macro = "INFLX_DIVH_PURE" if self.stager.pure_numerator(num, num_s, den[0], den_s[0]) else "INFLX_DIVH"
                 return f"{macro}({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
+            shared = self.stager.shared_reciprocal(den, den_s[0]) if self.stager is not None else None
+            if shared is not None:
+                return f"INFLX_DIVS({sign}{'*'.join(num_s)}, {den_s[0]}, {shared})"
             return sign + "*".join(num_s) + "/" + den_s[0]
-        return sign + "*".join(num_s) + "/(" + "*".join(den_s) + ")"
+        # a/(d1*d2*d3): C multiplies the denominator out first and divides once
+        den_text = "(" + "*".join(den_s) + ")"
+        shared = self.stager.shared_reciprocal(den, den_text) if self.stager is not None else None
+        if shared is not None:
+            return f"INFLX_DIVS({sign}{'*'.join(num_s)}, {den_text}, {shared})"
+        return sign + "*".join(num_s) + "/" + den_text
 
     def _print_Add(self, expr, order=None):
         terms = self._as_ordered_terms(expr, order=order)
@@ -298,7 +306,7 @@ class Stager:
     switch that mirrors the reference's five separate C functions.
     """
 
-    def __init__(self, functions, x0, x1, names, staged=True, regroup=False, hoist_reciprocals=False):
+    def __init__(self, functions, x0, x1, names, staged=True, regroup=False, hoist_reciprocals=False, shared_point_dens=()):
         """``functions``: one ``(replacements, [expressions])`` pair per generated C function of the
         reference (five scalar functions and the two-component basis vector ``v``), where
         ``replacements`` is the (possibly empty) list of ``(symbol, definition)`` pairs the
@@ -318,6 +326,9 @@ class Stager:
         self._count = defaultdict(int)
         self._by_text = {}  # (stage, right-hand side text) -> name of the variable that holds it
         self.range_terms = {U: {}, R: {}, C: {}}  # operand text -> E: |operand| must lie in [2^-E, 2^E] (pure hoisted quotients)
+        self.point_den_counts = Counter()  # text of a per-point denominator -> quotients of the point stage that divide by it
+        self.shared_point_dens = frozenset(shared_point_dens) if self.hoist_reciprocals else frozenset()
+        self._shared_recip = {}  # denominator text -> point-stage variable holding its refined reciprocal
         self._ctx = P
         self.refs = Counter()
         # identical nodes may be shared across the five functions only if no function-local
@@ -466,6 +477,28 @@ class Stager:
         if not d.free_symbols or self.mask(d) == P:
             return None
         return self._variable(_Group("recip", [d]), self.mask(d))
+
+    def shared_reciprocal(self, den, den_text):  # den: the factors of the denominator
+        """A quotient of the point stage by a PER-POINT denominator: counted, and -- when the same denominator (same
+        text, hence same value) serves several quotients and the first pass has said so -- divided through the shared
+        refined reciprocal ``INFLX_RCPN(den)`` (csrc/inflx_device_math.h: inflx_shared_reciprocal / inflx_div_by_shared,
+        the compiler's own division sequence with its reciprocal computed once).  Returns the variable's name or None."""
+        mask = 0
+        for d in den:
+            mask |= self.mask(d)
+        if not self.staged or self._ctx != P or mask != P:
+            return None
+        self.point_den_counts[den_text] += 1
+        if den_text not in self.shared_point_dens:
+            return None
+        name = self._shared_recip.get(den_text)
+        if name is None:
+            # (a numbering of its own: the p_k of the second pass must be the p_k of the first, whose texts selected the denominators)
+            name = f"y_{len(self._shared_recip)}"
+            self.stage_of[name] = P
+            self.lines[P].append(f"  const double {name} = INFLX_RCPN({den_text});")
+            self._shared_recip[den_text] = name
+        return self._reference(name)
 
     PURE_MAX_FACTORS = 4
     PURE_BUDGET = 480  # |log2| allowed for the whole numerator; a numerator of k factors allows 480/k per factor
@@ -638,6 +671,7 @@ class Stager:
 def emit_stage_header(
     model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False,
     hoist_reciprocals: bool = False,
+    share_point_reciprocals: bool = True,
 ):
     """Return (header text, info dict) for the model.
 
@@ -672,6 +706,11 @@ def emit_stage_header(
             functions.append(([], [e]))
     functions.append(cse_vector(basis_v) if cse_vector is not None else ([], basis_v))
     st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals)
+    if hoist_reciprocals and share_point_reciprocals:
+        # second pass: per-point denominators that serve several quotients get one shared reciprocal
+        several = [text for text, n in st.point_den_counts.items() if n >= 2]
+        if several:
+            st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals, shared_point_dens=several)
     range_flags = st.finish_range_flags()
 
     idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}
@@ -761,8 +800,9 @@ def emit_stage_header(
         lines.append("  INFLX_RANGE_CHECK(" + " + ".join(range_flags) + ");")
     point_body = "\n".join(place_imports(imports_for(P, "out"), lines))
     n_hoisted = point_body.count("INFLX_DIVH(") + point_body.count("INFLX_DIVH_PURE(")
+    n_shared = point_body.count("INFLX_DIVS(")
     out.append("// everything that depends on both axes, and the five model values")
-    if n_hoisted:
+    if n_hoisted or n_shared:
         # The same statements twice.  `quick` forms the quotients whose denominator comes from an earlier
         # stage with inflx_div_by_hoisted (three full-rate instructions instead of an IEEE division) and
         # reports in `ok` whether every one of them was a regular case; `ieee` divides.  A point that is not
@@ -774,17 +814,22 @@ def emit_stage_header(
         out.append("#define INFLX_DIVH(a, b, y) inflx_div_by_hoisted((a), (b), (y), ok)")
         out.append("#define INFLX_DIVH_PURE(a, b, y) inflx_div_by_hoisted_in_range((a), (b), (y))")
         out.append("#define INFLX_RANGE_CHECK(flags) ok = ok && ((flags) == 0.0)")
+        out.append(f"// {n_shared} quotients per point that share their per-point denominator with another one ({point_body.count('INFLX_RCPN(')} reciprocals)")
+        out.append("#define INFLX_RCPN(b) inflx_shared_reciprocal((b), ok)")
+        out.append("#define INFLX_DIVS(a, b, y) inflx_div_by_shared((a), (b), (y), ok)")
         out.append(f"INFLX_FN void inflx_stage_point_quick({point_args}, bool& ok) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n")
         out.append("#define INFLX_DIVH(a, b, y) ((a) / (b))")
+        out.append("#define INFLX_RCPN(b) 0.0")
+        out.append("#define INFLX_DIVS(a, b, y) ((a) / (b))")
         out.append("#define INFLX_DIVH_PURE(a, b, y) ((a) / (b))")
         out.append("#define INFLX_RANGE_CHECK(flags) (void)(flags)")
         out.append(f"INFLX_FN void inflx_stage_point_ieee({point_args}) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n")
         out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
         out.append("  bool ok = true;")
         out.append("  inflx_stage_point_quick(x0, x1, args, U, R, C, mv, ok);")
@@ -800,6 +845,9 @@ def emit_stage_header(
     info = dict(
         nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()},
         hoisted_quotients=sweep_lines.count("INFLX_DIVH(") + sweep_lines.count("INFLX_DIVH_PURE("),
+        pure_quotients=sweep_lines.count("INFLX_DIVH_PURE("),
+        shared_quotients=sweep_lines.count("INFLX_DIVS("),
+        shared_reciprocals=sweep_lines.count("INFLX_RCPN("),
     )  # fmt: skip
     return "\n".join(out), info
 

@@ -12,4 +12,4 @@ python3 $R/bench.py --steps 50 --warmup 5 > $O/bench.json 2> $O/bench.err || exi
 rocprofv3 --kernel-trace --stats -d $O/stats -o bench --output-format csv -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extras > $O/bench_under_rocprof.json 2> $O/stats.err || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc_write -o w --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_write.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc_fetch -o f --output-format csv -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > /dev/null 2> $O/pmc_fetch.err || exit 1
-python3 $R/scripts/profile_report.py $O ${1:-02}
+python3 $R/scripts/profile_report.py $O ${1:-03}

@@ -824,20 +824,27 @@ def test_large_geometries_equal_point_evaluation(name, n0, n1, P, op_name, layou
         assert np.array_equal(got, np.broadcast_to(got[:, :, :1], got.shape), equal_nan=True)
 
 
-@pytest.mark.parametrize("name", ["d5", "egno"])
+@pytest.mark.parametrize("name", ["d5", "egno", "doc", "angular"])
 def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
-    """Compiler(hoist_reciprocals=True): quotients by row/column/sweep-only denominators through Markstein's
-    step, irregular rows re-evaluated with IEEE divisions after the hot loop -- bit for bit the default
-    program's results, singular lines and NaN regions included."""
+    """Compiler(hoist_reciprocals=True), the quick point stage: quotients by row/column/sweep-only denominators
+    through Markstein's step, quotients that share a per-point denominator through one refined reciprocal, irregular
+    rows re-evaluated with IEEE divisions after the hot loop -- bit for bit the results of the program that divides
+    with the compiler's IEEE divisions everywhere, singular lines and NaN regions included."""
     import workloads
+    from inflatox_amd.compiler import Compiler
 
     spec, art0 = workloads.artifact_for(name, hoist_reciprocals=False)
     lib = gpu_lib.InflatoxDevLib(art0.shared_object_path)
-    _, art_h = workloads.artifact_for(name, hoist_reciprocals=True)
+    _, art_h = workloads.artifact_for(name, hoist_reciprocals=True, share_reciprocals=True)
     lib_h = gpu_lib.InflatoxDevLib(art_h.shared_object_path)
-    assert art_h.stage_info["hoisted_quotients"] >= 6 and art0.stage_info["hoisted_quotients"] == 0
-    # the default (automatic) choice: the hoisted program for D5 (29 quotients), the plain one for EGNO (12: does not pay)
-    assert devlib(name, gpu_lib)[1].stage_info["hoisted_quotients"] == (art_h.stage_info["hoisted_quotients"] if name == "d5" else 0)
+    info = art_h.stage_info
+    assert info["hoisted_quotients"] + info["shared_quotients"] >= 2 and art0.stage_info["hoisted_quotients"] == art0.stage_info["shared_quotients"] == 0
+    if name == "d5":
+        assert info["hoisted_quotients"] >= 20 and info["shared_quotients"] >= 8 and info["shared_reciprocals"] == 4
+    # the default (automatic) choice: the quick program (without shared per-point reciprocals) where it saves enough
+    # instructions per point -- D5 yes, the others no
+    auto = devlib(name, gpu_lib)[1].stage_info
+    assert auto["shared_quotients"] == 0 and auto["hoisted_quotients"] == (info["hoisted_quotients"] if name == "d5" else 0)
     ss = np.array(spec.extent).reshape(2, 2)
     wide = np.array([[spec.extent[0] - 0.3 * (spec.extent[1] - spec.extent[0]), spec.extent[1]], [spec.extent[2], spec.extent[3]]])
     # the third grid starts exactly at x1 = 0 and x0 = 0 where the models have them in range: structural zeros (a

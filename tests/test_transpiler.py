@@ -126,10 +126,10 @@ def test_fast_mode_is_close_but_not_exact(name):
 
     def point_divisions(h):
         # the IEEE variant of the point stage (or the only one): rational literals such as 1.0/3.0 are not
-        # divisions, a quotient by a hoisted reciprocal is one
+        # divisions, a quotient by a hoisted or shared reciprocal is one
         start = h.index("void inflx_stage_point_ieee(") if "inflx_stage_point_ieee" in h else h.index("void inflx_stage_point(")
         body = h[start : h.index("}\n", start)]
-        return body.count("/") - body.count(".0/") + body.count("INFLX_DIVH(")
+        return body.count("/") - body.count(".0/") + body.count("INFLX_DIVH(") + body.count("INFLX_DIVS(")
 
     if name != "doc":
         assert point_divisions(hdr) < point_divisions(exact_hdr), "fast mode should divide less often per grid point"
@@ -247,14 +247,19 @@ def test_hoisted_reciprocal_division_is_the_ieee_quotient(tmp_path):
 def test_hoisted_reciprocals_are_used_and_change_nothing(name):
     """The per-point divisions by row/column/sweep-only denominators go through inflx_div_by_hoisted, and the
     program with them is bit-identical to the one with plain divisions on the golden grid and random points."""
-    _, with_h = header_for(name, hoist_reciprocals=True)
+    forced, with_h = header_for(name, hoist_reciprocals=True, share_reciprocals=True)
     _, without = header_for(name, hoist_reciprocals=False)
-    assert "INFLX_DIVH(" in with_h and "inflx_stage_point_quick" in with_h and "INFLX_DIVH" not in without
-    # the automatic choice (hoist_reciprocals=None, the default): on where enough divisions leave the point stage
+    assert "INFLX_DIVH(" in with_h and "inflx_stage_point_quick" in with_h and "INFLX_DIVH" not in without and "INFLX_DIVS" not in without
+    # the automatic choice (hoist_reciprocals=None, the default): on where enough instructions leave the point stage
     _, auto = header_for(name)
-    assert auto == (with_h if name == "d5" else without)
+    plain, with_plain = header_for(name, hoist_reciprocals=True)  # without shared per-point reciprocals (the default)
+    gain = Compiler.quick_point_gain(plain.stage_info)
+    assert auto == (with_plain if gain >= Compiler.HOIST_MIN_GAIN else without) and "= INFLX_RCPN(" not in with_plain
+    assert (gain >= Compiler.HOIST_MIN_GAIN) == {"d5": True, "egno": False, "doc": False}[name], gain
     if name == "d5":
         assert "INFLX_DIVH_PURE(" in with_h and "r_flag" in with_h and "INFLX_RANGE_CHECK(u_flag + r_flag + c_flag)" in with_h
+        # four per-point denominators serve two or more quotients each: one refined reciprocal per denominator
+        assert with_h.count("= INFLX_RCPN(") == 2 * 4 and forced.stage_info["shared_quotients"] >= 8
     a, b = HostTwin(with_h), HostTwin(without)
     g = golden(name)
     n0, n1 = (int(v) for v in g["g64_shape"])
