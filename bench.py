@@ -161,6 +161,7 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
             rec = {
                 "workload": text,
                 "kernel": "inflx_sweep_tile_complete",
+                "build": "default: the reference's arithmetic (Compiler(...) as the reference's tests call it)",
                 "ms": ms,
                 "timing": f"HIP events around {repeats} back-to-back launches, best of 3 such batches",
                 "points_per_s": pps,
@@ -179,6 +180,24 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                     "valu_insts_per_point": ipp,
                     "source": src,
                 }
+            # the profile-guided build of the same workload (Compiler(regroup="auto", sample=(args, extent)): the model values
+            # that a host measurement on the workload's own parameter values and field range clears are re-associated;
+            # same parity criteria, tests/test_tuned_gpu.py) -- reported beside the default build, never instead of it
+            try:
+                _, art_t = workloads.artifact_for(name, tuned=True)
+                lib_t = _native.InflatoxDevLib(art_t.shared_object_path, device=device)
+                ms_t = min(lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
+                rec["profile_guided"] = {
+                    "build": 'Compiler(regroup="auto", sample=(args, extent))',
+                    "regrouped_values": art_t.stage_info.get("regrouped"),
+                    "ms": ms_t,
+                    "points_per_s": P * n * n / (ms_t * 1e-3),
+                    "hbm_frac": BYTES_PER_POINT * P * n * n / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                    "code_object": code_object_id(art_t),
+                }
+                del lib_t
+            except Exception as exc:  # noqa: BLE001
+                rec["profile_guided"] = {"error": str(exc)[:300]}
             out.append(rec)
             del buf, lib
             torch.cuda.empty_cache()

@@ -25,13 +25,14 @@ so a user's ``args`` array means the same thing here as there.
 from __future__ import annotations
 
 import hashlib
-import re
 import os
+import re
 import shutil
 import subprocess
 import sys
 import tempfile
 
+import numpy as np
 import sympy
 from sympy.printing.c import C99CodePrinter
 
@@ -266,7 +267,17 @@ class Compiler:
       the grid axes it depends on (staging.py); ``False`` evaluates everything per grid point;
     * ``regroup`` (default False): additionally re-associate mixed products/sums so that row-only
       and column-only operands are combined before the per-point ones (faster, but rounding differs
-      from the reference where a model cancels catastrophically);
+      from the reference where a model cancels catastrophically).  ``True`` regroups all five model values; a
+      collection of names out of ``"V", "v00", "v10", "v11", "g"`` (and ``"v"``, the basis vector of
+      ``flag_quantum_dif``) regroups those only and keeps the others -- and every sub-expression they share with a
+      regrouped one -- in the reference's arithmetic bit for bit.  ``"auto"`` (needs ``sample=(args, extent)``, the
+      parameter values and field range of the intended sweeps) MEASURES which values qualify: the generated code is
+      evaluated on the host on a sample of that range, the reference's form in float64 and in extended precision and
+      the regrouped form in float64, and a value is regrouped only if the regrouped form differs from the reference's by
+      less than 1e-10 relative plus four times the reference form's own rounding error at every sample point
+      (inflatox_amd/_instrument.py; a quarter of the smallest allowance the parity suite grants).  EGNO, the doc and the
+      angular model: all five values (EGNO 4096^2: 0.400 -> 0.321 ms); D5: V, v00 and |dV|^2 only -- its v10 is exact
+      in the reference's form at theta = k pi/4 where cancelling terms are equal bit for bit, and no other form is;
     * ``exact_constants`` (default False): full-precision pi, e, ... instead of the reference's
       12-digit fallback constants;
     * ``hoist_reciprocals`` (default None = automatic): a per-point quotient whose denominator is known one
@@ -348,10 +359,11 @@ class Compiler:
         compiler_flags: list[str] | None = None,
         staged: bool = True,
         exact_constants: bool = False,
-        regroup: bool = False,
+        regroup: bool | None = None,
         hoist_reciprocals: bool | None = None,
         tan_shortcut: float | None = None,
         share_reciprocals: bool = False,
+        sample=None,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -365,7 +377,28 @@ class Compiler:
         self.cse = cse
         self.max_cses = max_cses
         self.staged = staged
-        self.regroup = regroup
+        # (None: the environment variable INFLX_REGROUP, else off -- the switch the parity suite is run under for the
+        # regrouping experiments, profiles/r03_experiments.txt)
+        if regroup is None:
+            env = os.environ.get("INFLX_REGROUP", "0") or "0"
+            regroup = bool(int(env)) if env.isdigit() else tuple(env.split(","))
+        self.sample = None
+        if isinstance(regroup, str) and regroup == "auto":
+            if sample is None:
+                raise ValueError('regroup="auto" needs sample=(args, (x0_start, x0_stop, x1_start, x1_stop)): the parameter values and the field range the decision is measured on')
+            args_, extent_ = sample
+            self.sample = (np.ascontiguousarray(args_, dtype=np.float64).reshape(-1), tuple(float(v) for v in extent_))
+            if len(self.sample[1]) != 4:
+                raise ValueError("sample extent must be (x0_start, x0_stop, x1_start, x1_stop)")
+            self.regroup = "auto"  # resolved to a set of model values in _generate_hip_header
+        elif isinstance(regroup, (bool, int)):
+            self.regroup = bool(regroup)
+        else:
+            names = {"V": 0, "v00": 1, "v10": 2, "v11": 3, "g": 4, "v": 5}
+            unknown = [n for n in regroup if n not in names]
+            if unknown:
+                raise ValueError(f"regroup: unknown model value(s) {unknown}; choose from {sorted(names)}")
+            self.regroup = frozenset(names[n] for n in regroup)
         self.hoist_reciprocals = hoist_reciprocals
         self.share_reciprocals = bool(share_reciprocals)
         if tan_shortcut is None:
@@ -455,6 +488,23 @@ class Compiler:
             def cse_vector(vector):
                 return sympy.cse(list(vector), symbols=self._cse_symbols(), list=True)
 
+        if isinstance(self.regroup, str):  # "auto": measured on the sample, inflatox_amd/_instrument.py
+            from . import _instrument
+
+            def header_for(regroup):
+                saved, saved_info = self.regroup, self.stage_info
+                self.regroup = regroup
+                try:
+                    return self._generate_hip_header()
+                finally:
+                    self.regroup, self.stage_info = saved, saved_info
+
+            log = None if self.silent else (lambda msg: print("[regroup=auto] " + msg))
+            chosen = _instrument.choose_regroup(header_for, self.sample[0], self.sample[1], log=log)
+            self.regroup = frozenset(chosen)
+            self.regrouped_values = tuple(_instrument.NAMES[k] for k in sorted(chosen))
+            self.symbol_dict, params = self._number_parameters()
+
         def emit(hoist):
             return emit_stage_header(
                 self.symbolic_out,
@@ -481,6 +531,7 @@ class Compiler:
                 text, info = emit(False)
         else:
             text, info = emit(self.hoist_reciprocals)
+        info["regrouped"] = list(getattr(self, "regrouped_values", ())) if not isinstance(self.regroup, bool) else (["V", "v00", "v10", "v11", "g"] if self.regroup else [])
         self.stage_info = info
         return text
 

@@ -336,8 +336,32 @@ class Stager:
         share_across = all(not repl for repl, _ in functions)
         if share_across:
             self._count_refs([e for _, exprs in functions for e in exprs])
-        self.outputs, self.out_masks = [], []
-        for repl, exprs in functions:
+        # `regroup` may name the functions (positions in `functions`: 0 V, 1 v00, 2 v10, 3 v11, 4 |dV|^2, 5 the basis
+        # vector) whose products and sums may be re-associated; the others keep the reference's arithmetic bit for bit.
+        # Those are printed FIRST: a sub-expression they share with a regrouped function then exists in its exact form and
+        # the regrouped function reuses it, never the other way round.
+        regroup_set = None if isinstance(regroup, bool) else frozenset(regroup)
+        order = list(range(len(functions)))
+        if regroup_set is not None:
+            order.sort(key=lambda k: k in regroup_set)
+        slots = {}
+        for k in order:
+            repl, exprs = functions[k]
+            self.regroup = (k in regroup_set) if regroup_set is not None else bool(regroup)
+            self.outputs, self.out_masks = [], []
+            self._print_function(repl, exprs, share_across, staged)
+            slots[k] = (self.outputs, self.out_masks)
+        self.regroup = bool(regroup_set) if regroup_set is not None else bool(regroup)
+        self.outputs = [t for k in range(len(functions)) for t in slots[k][0]]
+        self.out_masks = [m for k in range(len(functions)) for m in slots[k][1]]
+        # the axis mask that selects the row-broadcast kernels covers the five values the sweeps use
+        self.out_mask = 0
+        for m in self.out_masks[:5]:
+            self.out_mask |= m
+        self.exports = {m: [n for n, s in self.stage_of.items() if s == m and (self.used_by[n] - {m})] for m in (U, R, C)}
+
+    def _print_function(self, repl, exprs, share_across, staged):
+        if True:
             if not share_across:
                 self.named, self._mask, self.refs, self.local = {}, {}, Counter(), {}
                 self._count_refs([d for _, d in repl] + list(exprs))
@@ -352,11 +376,6 @@ class Stager:
                 if text in self.stage_of:
                     self.used_by[text].add("out")
                 self.outputs.append(text)
-        # the axis mask that selects the row-broadcast kernels covers the five values the sweeps use
-        self.out_mask = 0
-        for m in self.out_masks[:5]:
-            self.out_mask |= m
-        self.exports = {m: [n for n, s in self.stage_of.items() if s == m and (self.used_by[n] - {m})] for m in (U, R, C)}
 
     def _count_refs(self, roots):
         if not self.staged:

@@ -323,3 +323,37 @@ def test_staged_header_on_host_matches_oracle_for_random_parameters(name):
         want = om.grid_sweep(oracle.OP.COMPLETE, args, ext, n0, n1)
         tol.check(tw.grid(4, args, ext, n0, n1), raw, tol.allowance_raw(raw, env, name), flaky, f"{name}/random {trial}/raw", model=name)
         tol.check(tw.grid(0, args, ext, n0, n1), want, tol.allowance_derived(raw, env, tol.epilogue, name), flaky.any(axis=-1)[..., None], f"{name}/random {trial}/out", model=name)
+
+
+@pytest.mark.parametrize("name", ["egno", "d5"])
+def test_profile_guided_regrouping_measures_which_values_qualify(name):
+    """Compiler(regroup="auto", sample=(args, extent)): the host instrument (inflatox_amd/_instrument.py) evaluates the
+    reference's form in float64 and in extended precision and the regrouped form in float64 on a sample of the workload
+    and clears a model value only if the regrouped form stays within 1e-10 relative + 4x the reference form's own
+    rounding error at every sample point.  EGNO: all five values.  D5: v10 is exact in the reference's form at theta =
+    k pi/4 (cancelling terms equal bit for bit) and v11 differs at a singular point -- both keep the reference's
+    arithmetic, bit for bit, while V, v00 and |dV|^2 are regrouped."""
+    from inflatox_amd import _instrument
+
+    if _instrument.host_compiler() is None or _instrument.HostModel(header_for("hyperbolic")[1], long_double=True).mantissa_bits <= 53:
+        pytest.skip("no host compiler / no extended-precision long double on this host")
+    spec = example_models.get(name)
+    c, hdr = header_for(name, regroup="auto", sample=(spec.args, spec.extent))
+    chosen = set(c.stage_info["regrouped"])
+    assert chosen == ({"V", "v00", "v10", "v11", "g"} if name == "egno" else {"V", "v00", "g"})
+    _, exact = header_for(name)
+    a, b = HostTwin(hdr), HostTwin(exact)
+    g = golden(name)
+    n0, n1 = (int(v) for v in g["g64_shape"])
+    x, y = a.grid(4, g["args"], g["g64_extent"], n0, n1), b.grid(4, g["args"], g["g64_extent"], n0, n1)
+    for k, value in enumerate(("V", "v00", "v10", "v11", "g")):
+        same = np.array_equal(x[..., k], y[..., k], equal_nan=True)
+        if value not in chosen:
+            assert same, f"{value} was not cleared for regrouping but differs from the default build"
+    assert not np.array_equal(x, y, equal_nan=True)  # something was regrouped
+    # and the regrouped build meets the parity criterion of the default one on the golden grid
+    env, flaky = tol.reference_error(name, g["args"], oracle.grid_points(g["g64_extent"], n0, n1))
+    env, flaky = env.reshape(n0, n1, 5), flaky.reshape(n0, n1, 5)
+    tol.check(x, g["g64_raw"], tol.allowance_raw(g["g64_raw"], env, name), flaky, f"{name}/g64/raw (regroup=auto)", model=name)
+    with pytest.raises(ValueError, match="sample"):
+        Compiler(workloads.model_for(name), silent=True, regroup="auto")

@@ -27,9 +27,14 @@ def model_for(name: str) -> InflationModel:
     return builder.build(spec.guesses)
 
 
-def artifact_for(name: str, **compiler_overrides) -> tuple[example_models.ModelSpec, CompilationArtifact]:
+def artifact_for(name: str, tuned: bool = False, **compiler_overrides) -> tuple[example_models.ModelSpec, CompilationArtifact]:
+    """``tuned``: the profile-guided build -- ``Compiler(regroup="auto", sample=(spec.args, spec.extent))``: products and
+    sums of the model values that qualify on a sample of the workload's own parameter values and field range are
+    re-associated (inflatox_amd/_instrument.py); the default is the reference's arithmetic."""
     spec = example_models.get(name)
     kwargs = dict(spec.compiler_kwargs)
+    if tuned:
+        kwargs.update(regroup="auto", sample=(spec.args, spec.extent))
     kwargs.update(compiler_overrides)
     art = Compiler(model_for(name), silent=True, **kwargs).compile()
     return spec, art
