@@ -132,7 +132,7 @@ def self_launch(opt) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
-def secondary_workloads(_native, workloads, torch, np, device, stream, only=None):
+def secondary_workloads(_native, workloads, torch, np, device, stream, only=None, builds=("default", "tuned")):
     """BASELINE configs[2] and [3] on this GPU, kernel time by HIP events on the launch stream (no part of `value`).
     These are FP64-VALU-bound: the roofline that prices them is the VALU issue rate, from
     the SQ instruction counters on record for exactly this code object; the HBM fraction is given beside it."""
@@ -154,7 +154,10 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
             buf = torch.empty((P, n, n, 6), dtype=torch.float64, device=f"cuda:{device}")
             # best of three batches of back-to-back launches: a single short batch sits inside the clock governor's
             # transient and reads 10-15 % slow
-            ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
+            if "default" in builds:
+                ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
+            else:  # scripts/secondary_probe.py NAME:tuned -- only the profile-guided build under the profiler
+                ms = float("nan")
             pps = P * n * n / (ms * 1e-3)
             cid = code_object_id(art)
             valu, src = recorded("valu", name, cid)
@@ -184,6 +187,8 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
             # that a host measurement on the workload's own parameter values and field range clears are re-associated;
             # same parity criteria, tests/test_tuned_gpu.py) -- reported beside the default build, never instead of it
             try:
+                if "tuned" not in builds:
+                    raise LookupError("not requested")
                 _, art_t = workloads.artifact_for(name, tuned=True)
                 lib_t = _native.InflatoxDevLib(art_t.shared_object_path, device=device)
                 ms_t = min(lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
@@ -196,6 +201,8 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                     "code_object": code_object_id(art_t),
                 }
                 del lib_t
+            except LookupError:
+                pass
             except Exception as exc:  # noqa: BLE001
                 rec["profile_guided"] = {"error": str(exc)[:300]}
             out.append(rec)
