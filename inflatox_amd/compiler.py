@@ -500,7 +500,26 @@ class Compiler:
                     self.regroup, self.stage_info = saved, saved_info
 
             log = None if self.silent else (lambda msg: print("[regroup=auto] " + msg))
-            chosen = _instrument.choose_regroup(header_for, self.sample[0], self.sample[1], log=log)
+            # the measurement takes a few host compiles: its outcome is cached next to the code objects, keyed by the
+            # reference form's header, the sample and the instrument's criterion
+            key = hashlib.sha256()
+            key.update(header_for(False).encode())
+            key.update(self.sample[0].tobytes() + np.asarray(self.sample[1], dtype=np.float64).tobytes())
+            key.update(repr((_instrument.RTOL, _instrument.C_ERR, _instrument.COPIES)).encode())
+            with open(_instrument.__file__, "rb") as fh:
+                key.update(fh.read())
+            decision_path = os.path.join(_cache_dir(), f"{key.hexdigest()[:20]}.regroup")
+            if os.path.exists(decision_path):
+                chosen = [int(t) for t in open(decision_path).read().split()]
+                if log:
+                    log("cached decision: " + ", ".join(_instrument.NAMES[k] for k in chosen))
+            else:
+                chosen = sorted(_instrument.choose_regroup(header_for, self.sample[0], self.sample[1], log=log))
+                if _instrument.host_compiler() is not None:  # "no information" outcomes are not cached
+                    tmp = decision_path + f".{os.getpid()}.tmp"
+                    with open(tmp, "w") as fh:
+                        fh.write(" ".join(str(k) for k in chosen) + "\n")
+                    os.replace(tmp, decision_path)
             self.regroup = frozenset(chosen)
             self.regrouped_values = tuple(_instrument.NAMES[k] for k in sorted(chosen))
             self.symbol_dict, params = self._number_parameters()
