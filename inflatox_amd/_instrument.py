@@ -40,6 +40,17 @@ def host_compiler() -> str | None:
     return None
 
 
+def _private_build_dir() -> str:
+    """A directory of this user's own (mode 0700) for the instrument's shared objects: they are dlopen'ed, so nobody
+    else may be able to place files there."""
+    d = os.path.join(tempfile.gettempdir(), f"inflx_instrument_{os.getuid()}")
+    os.makedirs(d, mode=0o700, exist_ok=True)
+    st = os.stat(d)
+    if st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        d = tempfile.mkdtemp(prefix="inflx_instrument_")  # somebody else's, or too open: a fresh private one (no reuse)
+    return d
+
+
 class HostModel:
     """A generated model header compiled for the host (``long_double``: every double read as long double)."""
 
@@ -48,8 +59,7 @@ class HostModel:
         if cxx is None:
             raise RuntimeError("no host C++ compiler for the conditioning instrument")
         tag = hashlib.sha256((header_text + str(long_double) + cxx).encode()).hexdigest()[:20]
-        d = os.path.join(tempfile.gettempdir(), "inflx_instrument")
-        os.makedirs(d, exist_ok=True)
+        d = _private_build_dir()
         hdr, so = os.path.join(d, f"{tag}.h"), os.path.join(d, f"{tag}.so")
         if not os.path.exists(so):
             with open(hdr + f".{os.getpid()}.tmp", "w") as fh:
