@@ -1105,3 +1105,31 @@ def test_broadcast_views_and_device_resident_result(gpu_lib):
     # the device-resident result of a tile-path model equals the host result bit for bit
     dev = al3.complete_analysis_device(spec_d.args, *spec_d.extent, 40, 36)
     assert all(np.array_equal(t.cpu().numpy(), x, equal_nan=True) for t, x in zip(dev, a))
+
+
+@pytest.mark.parametrize("name", ["doc", "egno"])
+def test_tan_shortcut_changes_eta_only_and_within_its_bound(name, gpu_lib):
+    """Compiler(tan_shortcut=16) (the default) takes tan(atan t) as t where t = |v10/v00| <= 16; tan_shortcut=0 evaluates
+    OCML's tan of OCML's atan.  The two builds agree bit for bit on consistency, eps_V, eps_H, delta and omega; eta =
+    omega*tan(delta) - 3 differs by at most ~(t + 1/t + 2) * 2^-53 relative on omega*tan(delta), only where t <= 16."""
+    import workloads
+
+    spec, art16 = workloads.artifact_for(name)
+    _, art0 = workloads.artifact_for(name, tan_shortcut=0)
+    a, b = gpu_lib.InflatoxDevLib(art0.shared_object_path), gpu_lib.InflatoxDevLib(art16.shared_object_path)
+    n0, n1 = 300, 520
+    exact = a.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1)
+    short = b.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1)
+    for k in (0, 1, 2, 4, 5):
+        assert np.array_equal(exact[..., k], short[..., k], equal_nan=True), k
+    assert np.array_equal(np.isnan(exact[..., 3]), np.isnan(short[..., 3]))
+    with np.errstate(all="ignore"):
+        t = np.tan(exact[..., 4])
+        product = np.abs(exact[..., 5] * t)
+        allowed = (t + 1.0 / np.maximum(t, 1e-300) + 4.0) * 2.0**-53 * product + 4 * np.spacing(np.abs(exact[..., 3]))
+        diff = np.abs(short[..., 3] - exact[..., 3])
+    fin = np.isfinite(exact[..., 3]) & np.isfinite(allowed)
+    assert (diff[fin] <= allowed[fin]).all(), float((diff[fin] / allowed[fin]).max())
+    above = fin & (t > 16.5)
+    assert np.array_equal(exact[..., 3][above], short[..., 3][above])  # beyond the bound both evaluate the tangent
+    assert (diff[fin] > 0).any()  # and the shortcut is really in use
