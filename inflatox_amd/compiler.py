@@ -550,7 +550,8 @@ class Compiler:
                 text, info = emit(False)
         else:
             text, info = emit(self.hoist_reciprocals)
-        info["regrouped"] = list(getattr(self, "regrouped_values", ())) if not isinstance(self.regroup, bool) else (["V", "v00", "v10", "v11", "g"] if self.regroup else [])
+        value_names = ("V", "v00", "v10", "v11", "g")
+        info["regrouped"] = (list(value_names) if self.regroup else []) if isinstance(self.regroup, bool) else [value_names[k] for k in sorted(self.regroup) if k < 5]
         self.stage_info = info
         return text
 
