@@ -153,6 +153,30 @@ __device__ __forceinline__ bool apply_op_quick(const InflxModelValues& mv, doubl
   }
 }
 
+// One 16-byte store of a store stream (row / column broadcast paths), with its cache-policy bits spelled out.
+// scripts/micro/store_bw.hip, variant Q, 3.2 GB of 16-byte stores, one per thread (profiles/r03_store_policy.txt):
+// no bits 6.86-6.91 TB/s, `nt` (what __builtin_nontemporal_store emits) 6.71, `sc1` 7.06-7.09, `sc0 sc1` 7.06-7.09,
+// `sc1 nt` 7.03-7.04, `sc0 sc1 nt` 7.06 -- the system-scope bit is worth 5 % over the plain streaming hint.  The streaming
+// hint stays: without it the stream sweeps the row table out of the Infinity Cache (section 4.1 of DESIGN.md): in the product
+// kernel, hyperbolic 8192^2, `nt` 0.463 ms, `sc1 nt` 0.445, `sc0 sc1 nt` 0.444, `sc1` / `sc0 sc1` 0.668.  (The tile kernels'
+// stores gain nothing from it -- doc 0.212 -> 0.216 ms, D5 0.438 -> 0.486 with the asm spelling -- and keep the builtin.)
+#ifndef INFLX_STREAM_STORE
+#define INFLX_STREAM_STORE 1
+#endif
+__device__ __forceinline__ void stream_store_d2(inflx_d2* p, inflx_d2 v) {
+#if INFLX_STREAM_STORE == 0
+  __builtin_nontemporal_store(v, p);
+#elif INFLX_STREAM_STORE == 1
+  asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+#elif INFLX_STREAM_STORE == 2
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+#elif INFLX_STREAM_STORE == 3
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+#endif
+}
+
 __device__ __forceinline__ void store_d2(double* p, inflx_d2 v) {
 #if INFLX_NT_STORES
   __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(p));
@@ -533,7 +557,7 @@ __device__ __forceinline__ void sweep_rowstream6(const InflxSweepArgs& a) {
   // non-temporal on purpose: a plain store stream of 3.2 GB sweeps the row table out of the Infinity
   // Cache, every table fetch then goes to HBM and the stream drops to 5.0 TB/s; with nt stores the
   // table stays cached and the stream runs at 6.7-6.8 TB/s (scripts/micro/store_bw.hip, variants G/H/P)
-  if (u < units_row) __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(a.out + slab_row * a.N1 * 6 + 2 * u));
+  if (u < units_row) stream_store_d2(reinterpret_cast<inflx_d2*>(a.out + slab_row * a.N1 * 6 + 2 * u), v);
 }
 static_assert(kThreads % 3 == 1, "the phase rule of sweep_rowstream6 needs kThreads == 1 (mod 3)");
 
@@ -552,7 +576,7 @@ __device__ __forceinline__ void sweep_rowstream_planes(const InflxSweepArgs& a) 
   asm volatile("" : "+s"(v));
   const uint64_t u = (uint64_t)piece * kThreads + threadIdx.x;
   double* dst = a.out + (((uint64_t)p * a.stream_planes + k) * a.row_count + row) * a.N1;
-  if (u < units_row) __builtin_nontemporal_store(inflx_d2{v, v}, reinterpret_cast<inflx_d2*>(dst + 2 * u));
+  if (u < units_row) stream_store_d2(reinterpret_cast<inflx_d2*>(dst + 2 * u), inflx_d2{v, v});
 }
 
 template <int OP>
@@ -651,7 +675,7 @@ __device__ __forceinline__ void sweep_colstream(const InflxSweepArgs& a) {
   const uint64_t z = blockIdx.z;
   if (u < a.stream_units) {
     const inflx_d2 v = reinterpret_cast<const inflx_d2*>(a.row_table)[z * a.stream_units + u];
-    __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(a.out) + (z * a.row_count + row) * a.stream_units + u);
+    stream_store_d2(reinterpret_cast<inflx_d2*>(a.out) + (z * a.row_count + row) * a.stream_units + u, v);
   }
 }
 

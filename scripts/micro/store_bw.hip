@@ -73,6 +73,22 @@ template <bool NT, int THREADS> __global__ __launch_bounds__(THREADS) void one_s
   if (u < total_units) st<NT>(out + 2 * u, v);
 }
 
+// Q (round 3): F with the store's cache-policy bits spelled explicitly (gfx950: sc0 / sc1 = coherence scope, nt = streaming hint)
+template <int POLICY> __global__ __launch_bounds__(256) void one_store_policy(double* out, uint64_t total_units) {
+  const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  d2 v = {1.0 + threadIdx.x, 2.0};
+  if (u >= total_units) return;
+  double* p = out + 2 * u;
+  if (POLICY == 0) asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 1) asm volatile("global_store_dwordx4 %0, %1, off nt" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 2) asm volatile("global_store_dwordx4 %0, %1, off sc0" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 3) asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 4) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 5) asm volatile("global_store_dwordx4 %0, %1, off sc0 nt" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 6) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(p), "v"(v) : "memory");
+  if (POLICY == 7) asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1 nt" : : "v"(p), "v"(v) : "memory");
+}
+
 // X: F with an XCD-aware remap of workgroup -> 4-KiB piece: workgroups are dispatched round-robin over the 8 XCDs
 // (blockIdx % 8), so with run = G consecutive pieces per XCD each XCD's L2 write-combines contiguous runs of G * 4 KiB;
 // G = nblocks/8 gives every XCD one contiguous eighth of the buffer, G = 1 is F itself
@@ -145,8 +161,9 @@ template <int S> __global__ __launch_bounds__(256) void rowstream_cold(const GAr
   }
 }
 
-int main() {
+int main(int argc, char** argv) {
   setvbuf(stdout, NULL, _IONBF, 0);
+  const bool policy_only = argc > 1 && argv[1][0] == 'p';  // `store_bw.bin policy`: only the cache-policy variants Q
   const uint64_t N = 8192, upr = 3 * N, rows = N, total = rows * upr;
   const size_t bytes = total * 16;
   double* d; CK(hipMalloc(&d, bytes));
@@ -163,6 +180,16 @@ int main() {
     }
     printf("%-44s %7.3f ms  %7.1f GB/s\n", name, best, bytes / best / 1e6);
   };
+  {
+    const unsigned nb = (unsigned)((total + 255) / 256);
+    const char* names[8] = {"(none)", "nt", "sc0", "sc1", "sc0 sc1", "sc0 nt", "sc1 nt", "sc0 sc1 nt"};
+    for (int round = 0; round < 2; ++round) {
+      char nm[96];
+#define RUN_Q(P) snprintf(nm, sizeof nm, "Q 1 store/thread 256thr, policy %s", names[P]); timeit(nm, [&] { one_store_policy<P><<<nb, 256>>>(d, total); });
+      RUN_Q(0) RUN_Q(1) RUN_Q(2) RUN_Q(3) RUN_Q(4) RUN_Q(5) RUN_Q(6) RUN_Q(7)
+    }
+  }
+  if (policy_only) return 0;
   timeit("A wave/row nt", [&] { wave_per_row<true><<<rows / 4, 256>>>(d, rows, upr); });
   timeit("A wave/row plain", [&] { wave_per_row<false><<<rows / 4, 256>>>(d, rows, upr); });
   timeit("C block/row nt", [&] { block_per_row<true><<<rows, 256>>>(d, rows, upr); });
