@@ -74,8 +74,13 @@ template <bool NT, int THREADS> __global__ __launch_bounds__(THREADS) void one_s
 }
 
 // Q (round 3): F with the store's cache-policy bits spelled explicitly (gfx950: sc0 / sc1 = coherence scope, nt = streaming hint)
-template <int POLICY> __global__ __launch_bounds__(256) void one_store_policy(double* out, uint64_t total_units) {
-  const uint64_t u = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+template <int POLICY, int THREADS = 256, int PER_THREAD = 1> __global__ __launch_bounds__(THREADS) void one_store_policy(double* out, uint64_t total_units) {
+  uint64_t u = (uint64_t)blockIdx.x * (THREADS * PER_THREAD) + threadIdx.x;
+  if (PER_THREAD == 2) {  // two stores per thread, THREADS * 16 bytes apart: 2 * THREADS * 16 contiguous bytes per workgroup
+    d2 w = {3.0 + threadIdx.x, 4.0};
+    double* q = out + 2 * (u + THREADS);
+    if (u + THREADS < total_units) asm volatile("global_store_dwordx4 %0, %1, off sc1 nt" : : "v"(q), "v"(w) : "memory");
+  }
   d2 v = {1.0 + threadIdx.x, 2.0};
   if (u >= total_units) return;
   double* p = out + 2 * u;
@@ -188,6 +193,12 @@ int main(int argc, char** argv) {
 #define RUN_Q(P) snprintf(nm, sizeof nm, "Q 1 store/thread 256thr, policy %s", names[P]); timeit(nm, [&] { one_store_policy<P><<<nb, 256>>>(d, total); });
       RUN_Q(0) RUN_Q(1) RUN_Q(2) RUN_Q(3) RUN_Q(4) RUN_Q(5) RUN_Q(6) RUN_Q(7)
     }
+  }
+  {
+    char nm[96];
+#define RUN_QT(T, PT) snprintf(nm, sizeof nm, "Q sc1 nt, %d threads, %d store(s)/thread (%d KiB/workgroup)", T, PT, T * PT * 16 / 1024); \
+    timeit(nm, [&] { one_store_policy<6, T, PT><<<(unsigned)((total + (uint64_t)T * PT - 1) / ((uint64_t)T * PT)), T>>>(d, total); });
+    for (int round = 0; round < 2; ++round) { RUN_QT(64, 1) RUN_QT(128, 1) RUN_QT(256, 1) RUN_QT(512, 1) RUN_QT(1024, 1) RUN_QT(256, 2) RUN_QT(128, 2) }
   }
   if (policy_only) return 0;
   timeit("A wave/row nt", [&] { wave_per_row<true><<<rows / 4, 256>>>(d, rows, upr); });
