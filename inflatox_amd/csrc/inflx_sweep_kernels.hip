@@ -160,6 +160,9 @@ __device__ __forceinline__ bool apply_op_quick(const InflxModelValues& mv, doubl
 // hint stays: without it the stream sweeps the row table out of the Infinity Cache (section 4.1 of DESIGN.md): in the product
 // kernel, hyperbolic 8192^2, `nt` 0.463 ms, `sc1 nt` 0.445, `sc0 sc1 nt` 0.444, `sc1` / `sc0 sc1` 0.668.  (The tile kernels'
 // stores gain nothing from it -- doc 0.212 -> 0.216 ms, D5 0.438 -> 0.486 with the asm spelling -- and keep the builtin.)
+#ifndef INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP
+#define INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP 1
+#endif
 #ifndef INFLX_STREAM_STORE
 #define INFLX_STREAM_STORE 1
 #endif
@@ -177,25 +180,27 @@ __device__ __forceinline__ void stream_store_d2(inflx_d2* p, inflx_d2 v) {
 #endif
 }
 
-__device__ __forceinline__ void store_d2(double* p, inflx_d2 v) {
+__device__ __forceinline__ void store_d2(inflx_d2* p, inflx_d2 v) {
 #if INFLX_NT_STORES
-  __builtin_nontemporal_store(v, reinterpret_cast<inflx_d2*>(p));
+  __builtin_nontemporal_store(v, p);
 #else
-  *reinterpret_cast<inflx_d2*>(p) = v;
+  *p = v;
 #endif
 }
 
 // one scalar result at element offset `off`: an f64, or for the boolean flag sweep one byte
 // (the reference fills a numpy bool array, consistency_conditions.py:515)
+// `off` is wave-uniform and `lane_off` a 32-bit per-thread offset: the address is "scalar base + vector offset", which the
+// store instruction forms by itself (no 64-bit pointer arithmetic per lane)
 template <int OP>
-__device__ __forceinline__ void store_scalar(double* out, uint64_t off, double v) {
+__device__ __forceinline__ void store_scalar(double* out, uint64_t off, unsigned lane_off, double v) {
   if constexpr (OP == INFLX_OP_QDIF) {
-    reinterpret_cast<uint8_t*>(out)[off] = v != 0.0 ? 1 : 0;
+    (reinterpret_cast<uint8_t*>(out) + off)[lane_off] = v != 0.0 ? 1 : 0;
   } else {
 #if INFLX_NT_STORES
-    __builtin_nontemporal_store(v, out + off);
+    __builtin_nontemporal_store(v, out + off + lane_off);
 #else
-    out[off] = v;
+    (out + off)[lane_off] = v;
 #endif
   }
 }
@@ -347,11 +352,20 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   __syncthreads();
 #endif
 
+#if INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP
+  // Every vector-memory LOAD of this kernel is issued above (parameters, the column values); the row loop only stores.
+  // gfx950 counts loads and stores in the same counter (vmcnt), and the compiler waits for a load at the first use of its
+  // value -- inside the row loop, where "vmcnt(0)" also means "until every store of the previous grid row has been
+  // acknowledged by memory": each wavefront then idles one write round trip per row.  Waiting here, once, leaves the loop
+  // without any wait on the stores.
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0), expcnt and lgkmcnt untouched
+#endif
   const bool in_range = j < a.N1;
   const uint64_t wave_col0 = col0 + (uint64_t)wave * kWave;
   // 16-byte units of this wavefront's 64-point block that lie inside the row (AoS, K = 6)
   const uint64_t cols_left = wave_col0 < a.N1 ? a.N1 - wave_col0 : 0;
   const unsigned wave_units = cols_left >= kWave ? 3u * kWave : 3u * (unsigned)cols_left;
+  const unsigned wave_unit0 = wave * (3u * kWave);  // first unit of the wavefront's block within the workgroup's part of a row
 
   // what happens to the K values of one grid row: summary, then the store in the requested layout
   auto emit = [&](const double (&o)[K], const uint64_t row) {
@@ -360,12 +374,16 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     }
     if constexpr (!STORE) return;
 
+    // Every address below is "wave-uniform row base + 32-bit offset of the thread": the stores then take the base from
+    // scalar registers and the compiler neither keeps 64-bit per-lane pointers across the row loop nor advances them
+    // every row (it kept seven -- six planes and the AoS block -- when the addresses were formed per lane: 14 vector
+    // registers and 7 64-bit additions per grid row, whichever layout ran).
     if (a.layout == INFLX_LAYOUT_SOA || K == 1) {
       if (in_range) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j;
-          store_scalar<OP>(a.out, off, o[k]);
+          const uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + col0;
+          store_scalar<OP>(a.out, off, tid, o[k]);
         }
       }
     } else if constexpr (K == 6) {
@@ -379,7 +397,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + wave_col0) * 6;
+      inflx_d2* dst = reinterpret_cast<inflx_d2*>(a.out + (((uint64_t)p * a.row_count + row) * a.N1 + col0) * 6);  // the workgroup's 12 KiB of this row
       const inflx_d2* units = reinterpret_cast<const inflx_d2*>(tb);
       // all three LDS reads are issued before the first (predicated) store: one LDS round trip per row
       // instead of three (left alone, the compiler sinks every read into its store's branch)
@@ -392,16 +410,16 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #pragma unroll
       for (int s = 0; s < 3; ++s) {
         const unsigned q = s * kWave + lane;
-        if (q < wave_units) store_d2(dst + 2 * q, v[s]);
+        if (q < wave_units) store_d2(dst + (wave_unit0 + q), v[s]);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
       if (in_range) {
-        double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + j) * K;
+        double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + col0) * K;
 #pragma unroll
-        for (int k = 0; k < K; ++k) store_d1(dst + k, o[k]);
+        for (int k = 0; k < K; ++k) store_d1(dst + (tid * (unsigned)K + k), o[k]);
       }
     }
   };
@@ -616,7 +634,7 @@ __device__ __forceinline__ void sweep_rows(const InflxSweepArgs& a) {
       for (int k = 0; k < K; ++k) {
         const uint64_t off = a.layout == INFLX_LAYOUT_SOA ? (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + j
                                                           : (((uint64_t)p * a.row_count + row) * a.N1 + j) * K + k;
-        store_scalar<OP>(a.out, off, v[k]);
+        store_scalar<OP>(a.out, off, 0u, v[k]);
       }
     }
   }
@@ -700,7 +718,7 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   double o[K];
   apply_op<OP>(mv, o, a.accuracy);
 #pragma unroll
-  for (int k = 0; k < K; ++k) store_scalar<OP>(a.out, ((uint64_t)p * a.n + idx) * K + k, o[k]);
+  for (int k = 0; k < K; ++k) store_scalar<OP>(a.out, ((uint64_t)p * a.n + idx) * K + k, 0u, o[k]);
 }
 
 // ================================================================================================

@@ -1,6 +1,7 @@
 """The epilogue's specialised atan / tan (csrc/inflx_ops.h: OCML's algorithms restricted to the arguments
 ops::complete_analysis can produce, src/anguelova.rs:128,132) equal OCML's general atan / tan bit for bit on that
-domain -- 16 million arguments compared on the device, the special values included."""
+domain -- 16 million arguments compared on the device, the special values included -- and so does the quick epilogue's
+square root (the compiler's sqrt without operand scaling, behind a range guard)."""
 
 import os
 import subprocess
@@ -24,3 +25,5 @@ def test_specialised_atan_and_tan_equal_ocml_bit_for_bit(gpu_lib, tmp_path, horn
     proc = subprocess.run([str(exe), "16"], capture_output=True, text=True, timeout=600)
     assert proc.returncode == 0, proc.stdout + proc.stderr
     assert "atan mismatches 0, tan mismatches 0" in proc.stdout, proc.stdout
+    # the quick epilogue's square root (inflx_sqrt_quick) equals the compiler's wherever its guard accepts the argument
+    assert ", mismatches 0\n" in proc.stdout and "quick sqrt:" in proc.stdout, proc.stdout
