@@ -293,6 +293,12 @@ class Compiler:
       divides four times by ``r_44*p_5``) share one refined reciprocal (csrc/inflx_device_math.h).  Exact, and 32 fewer
       instructions per point for D5 -- but the additional comparisons and live values cost as much again (SGPR spills,
       three wavefronts per SIMD no longer fit): 13.9 -> 14.8 ms for D5 4096^2 x 32, hence off (profiles/r03_experiments.txt).
+    * ``quick_sqrt`` (default ``None``): the point stage's square roots without the compiler's operand scaling and zero /
+      infinity selection, behind one range test each (``inflx_sqrt_checked``; exact, like the hoisted reciprocals: a value
+      outside the guard sends the grid row to the IEEE variant of the stage).  Eight instructions fewer per root -- and a
+      second copy of the point stage plus the ``ok`` bookkeeping for models that would not have them otherwise: measured
+      4096^2, doc 0.216 -> 0.218 ms, angular 0.256 -> 0.261, EGNO 0.403 -> 0.416 (148 -> 168 VGPRs), D5 0.446 -> 0.438.  ``None``
+      therefore switches it on exactly where the quick point stage exists anyway (hoisted reciprocals on: D5).
     * ``tan_shortcut`` (default 16; 0 = off; ``None`` reads the environment variable ``INFLX_TAN_SHORTCUT``, else the default): the epilogue's
       ``tan(atan(t))``, t = |v10/v00| (src/anguelova.rs:128,132), is taken as ``t`` itself wherever ``t <= tan_shortcut``.
       The reference's two libm calls return t(1 + e) with |e| <~ (t + 1/t)*2^-53, so the results differ from those of
@@ -364,6 +370,7 @@ class Compiler:
         tan_shortcut: float | None = None,
         share_reciprocals: bool = False,
         sample=None,
+        quick_sqrt: bool | None = None,
     ):
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
@@ -401,6 +408,7 @@ class Compiler:
             self.regroup = frozenset(names[n] for n in regroup)
         self.hoist_reciprocals = hoist_reciprocals
         self.share_reciprocals = bool(share_reciprocals)
+        self.quick_sqrt = quick_sqrt  # None: wherever the quick point stage exists anyway (see the class docstring)
         if tan_shortcut is None:
             tan_shortcut = float(os.environ.get("INFLX_TAN_SHORTCUT", "") or self.DEFAULT_TAN_SHORTCUT)
         if tan_shortcut < 0 or tan_shortcut != int(tan_shortcut) or tan_shortcut >= 2**17:
@@ -538,6 +546,7 @@ class Compiler:
                 regroup=self.regroup,
                 hoist_reciprocals=hoist,
                 share_point_reciprocals=self.share_reciprocals,
+                quick_sqrt=bool(hoist) if self.quick_sqrt is None else bool(self.quick_sqrt),
             )
 
         if self.hoist_reciprocals is None:

@@ -110,34 +110,7 @@ INFLX_FN double inflx_reciprocal_quick(double b) {
 }
 // biased exponent field of a double: 0 for zeros and denormals, 2047 for infinities and NaNs
 INFLX_FN unsigned inflx_exponent_field(double x) { return ((unsigned)__double2hiint(x) >> 20) & 0x7ffu; }
-// High word of |x|: exponent field and the top 20 bits of the significand as one unsigned number, monotonic in |x|
-// (field >= E  <=>  word >= E << 20): a range test of one value is an AND, a subtraction and an unsigned comparison.
-// (Spelling the five-value test of the quick epilogue this way as well -- v_min3 / v_max3 over the words instead of the
-// extracted fields, 11 instructions for the compiler's 25 -- changes nothing measurable for doc, angular and EGNO and
-// costs D5 twelve more spilled registers, profiles/r03_experiments.txt section 10: it keeps the fields.)
-INFLX_FN unsigned inflx_magnitude_word(double x) { return (unsigned)__double2hiint(x) & 0x7fffffffu; }
-constexpr unsigned inflx_field_word(unsigned field) { return field << 20; }
-
-// sqrt(x) as the compiler spells it (v_rsq_f64, then Goldschmidt's coupled iteration and two residual corrections),
-// WITHOUT the operand scaling (x < 2^-767 is multiplied by 2^256 first, the root by 2^-128 afterwards) and without the
-// final selection that returns x itself for zeros and +infinity: eight instructions fewer.  Bit for bit the compiler's
-// result for every x with 2^-767 <= |x| < infinity -- for negative x both spellings return the NaN of v_rsq_f64 -- which
-// the caller establishes (inflx_sqrt_quick_ok).
-INFLX_FN double inflx_sqrt_quick(double x) {
-#pragma clang fp contract(off)
-  const double y = __builtin_amdgcn_rsq(x);
-  double g = x * y;
-  double h = y * 0.5;
-  const double r = __builtin_fma(-h, g, 0.5);
-  g = __builtin_fma(g, r, g);
-  h = __builtin_fma(h, r, h);
-  const double d0 = __builtin_fma(-g, g, x);
-  g = __builtin_fma(d0, h, g);
-  const double d1 = __builtin_fma(-g, g, x);
-  return __builtin_fma(d1, h, g);
-}
-// exponent field of x in [1023 - 767, 2046]: one subtraction and one unsigned comparison of the magnitude word
-INFLX_FN bool inflx_sqrt_quick_ok(double x) { return inflx_magnitude_word(x) - inflx_field_word(1023u - 767u) < inflx_field_word(2047u - (1023u - 767u)); }
+// (inflx_magnitude_word, inflx_field_word, inflx_sqrt_quick and inflx_sqrt_quick_ok: inflx_device_math.h)
 
 // Wave-uniform specialisation (both functions below).  Along a grid row delta = atan|v10/v00| varies smoothly, so the 64
 // lanes of a wavefront nearly always sit on the same side of t = 1 (delta = pi/4): measured on the 4096-column grids of

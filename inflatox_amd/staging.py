@@ -51,6 +51,8 @@ U, R, C, P = 0, 1, 2, 3
 STAGE_PREFIX = {U: "u", R: "r", C: "c", P: "p"}
 ARRAY = {U: "U", R: "R", C: "C"}
 _STAGE_NAME = re.compile(r"\b[urcp]_\d+\b")
+_SQRT_CALL = re.compile(r"(?<![A-Za-z0-9_])sqrt\(")
+_HPOW_CALL = re.compile(r"(?<![A-Za-z0-9_])inflx_hpow<(\d+)>\(")
 OUTPUT_FIELDS = ("V", "v00", "v10", "v11", "g", "b0", "b1")
 
 
@@ -691,6 +693,7 @@ def emit_stage_header(
     model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False,
     hoist_reciprocals: bool = False,
     share_point_reciprocals: bool = True,
+    quick_sqrt: bool = True,
 ):
     """Return (header text, info dict) for the model.
 
@@ -820,8 +823,14 @@ def emit_stage_header(
     point_body = "\n".join(place_imports(imports_for(P, "out"), lines))
     n_hoisted = point_body.count("INFLX_DIVH(") + point_body.count("INFLX_DIVH_PURE(")
     n_shared = point_body.count("INFLX_DIVS(")
+    # square roots of the point stage: the quick variant takes them without operand scaling and zero / infinity selection
+    # behind one range test each (inflx_sqrt_checked, csrc/inflx_device_math.h)
+    if quick_sqrt:
+        point_body = _SQRT_CALL.sub("INFLX_SQRT(", point_body)
+        point_body = _HPOW_CALL.sub(lambda m: f"INFLX_HPOW({m.group(1)}, ", point_body)
+    n_sqrt = point_body.count("INFLX_SQRT(") + point_body.count("INFLX_HPOW(")
     out.append("// everything that depends on both axes, and the five model values")
-    if n_hoisted or n_shared:
+    if n_hoisted or n_shared or n_sqrt:
         # The same statements twice.  `quick` forms the quotients whose denominator comes from an earlier
         # stage with inflx_div_by_hoisted (three full-rate instructions instead of an IEEE division) and
         # reports in `ok` whether every one of them was a regular case; `ieee` divides.  A point that is not
@@ -836,10 +845,15 @@ def emit_stage_header(
         out.append(f"// {n_shared} quotients per point that share their per-point denominator with another one ({point_body.count('INFLX_RCPN(')} reciprocals)")
         out.append("#define INFLX_RCPN(b) inflx_shared_reciprocal((b), ok)")
         out.append("#define INFLX_DIVS(a, b, y) inflx_div_by_shared((a), (b), (y), ok)")
+        out.append(f"// {n_sqrt} square roots per point without their special-case handling")
+        out.append("#define INFLX_SQRT(x) inflx_sqrt_checked((x), ok)")
+        out.append("#define INFLX_HPOW(n, x) inflx_hpow_checked<n>((x), ok)")
         out.append(f"INFLX_FN void inflx_stage_point_quick({point_args}, bool& ok) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n#undef INFLX_SQRT\n#undef INFLX_HPOW\n")
+        out.append("#define INFLX_SQRT(x) sqrt(x)")
+        out.append("#define INFLX_HPOW(n, x) inflx_hpow<n>(x)")
         out.append("#define INFLX_DIVH(a, b, y) ((a) / (b))")
         out.append("#define INFLX_RCPN(b) 0.0")
         out.append("#define INFLX_DIVS(a, b, y) ((a) / (b))")
@@ -848,7 +862,7 @@ def emit_stage_header(
         out.append(f"INFLX_FN void inflx_stage_point_ieee({point_args}) {{")
         out.append(point_body)
         out.append("}")
-        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n")
+        out.append("#undef INFLX_DIVH\n#undef INFLX_DIVH_PURE\n#undef INFLX_RANGE_CHECK\n#undef INFLX_RCPN\n#undef INFLX_DIVS\n#undef INFLX_SQRT\n#undef INFLX_HPOW\n")
         out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
         out.append("  bool ok = true;")
         out.append("  inflx_stage_point_quick(x0, x1, args, U, R, C, mv, ok);")
@@ -867,6 +881,7 @@ def emit_stage_header(
         pure_quotients=sweep_lines.count("INFLX_DIVH_PURE("),
         shared_quotients=sweep_lines.count("INFLX_DIVS("),
         shared_reciprocals=sweep_lines.count("INFLX_RCPN("),
+        quick_square_roots=sweep_lines.count("INFLX_SQRT(") + sweep_lines.count("INFLX_HPOW("),
     )  # fmt: skip
     return "\n".join(out), info
 

@@ -256,6 +256,14 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
     gain = Compiler.quick_point_gain(plain.stage_info)
     assert auto == (with_plain if gain >= Compiler.HOIST_MIN_GAIN else without) and "= INFLX_RCPN(" not in with_plain
     assert (gain >= Compiler.HOIST_MIN_GAIN) == {"d5": True, "egno": False, "doc": False}[name], gain
+    # the point stage's square roots take the guarded spelling exactly where the quick stage exists (quick_sqrt=None), or on request
+    roots = {"d5": 3, "egno": 4, "doc": 1}[name]
+    assert with_h.count("INFLX_SQRT(x)") == 2 and forced.stage_info["quick_square_roots"] == roots
+    assert "INFLX_SQRT" not in without and "INFLX_HPOW" not in without
+    asked, on_request = header_for(name, hoist_reciprocals=False, quick_sqrt=True)
+    assert asked.stage_info["quick_square_roots"] == roots and asked.stage_info["hoisted_quotients"] == 0 and "inflx_stage_point_quick" in on_request
+    never, _ = header_for(name, hoist_reciprocals=True, quick_sqrt=False)
+    assert never.stage_info["quick_square_roots"] == 0 and never.stage_info["hoisted_quotients"] > 0
     if name == "d5":
         assert "INFLX_DIVH_PURE(" in with_h and "r_flag" in with_h and "INFLX_RANGE_CHECK(u_flag + r_flag + c_flag)" in with_h
         # four per-point denominators serve two or more quotients each: one refined reciprocal per denominator
