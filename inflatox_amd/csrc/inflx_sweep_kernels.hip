@@ -160,6 +160,14 @@ __device__ __forceinline__ bool apply_op_quick(const InflxModelValues& mv, doubl
 // hint stays: without it the stream sweeps the row table out of the Infinity Cache (section 4.1 of DESIGN.md): in the product
 // kernel, hyperbolic 8192^2, `nt` 0.463 ms, `sc1 nt` 0.445, `sc0 sc1 nt` 0.444, `sc1` / `sc0 sc1` 0.668.  (The tile kernels'
 // stores gain nothing from it -- doc 0.212 -> 0.216 ms, D5 0.438 -> 0.486 with the asm spelling -- and keep the builtin.)
+#ifndef INFLX_OPAQUE_ROW_BASE
+#define INFLX_OPAQUE_ROW_BASE 1
+#endif
+#if INFLX_OPAQUE_ROW_BASE
+#define INFLX_KEEP_SCALAR(x) asm volatile("" : "+s"(x))
+#else
+#define INFLX_KEEP_SCALAR(x) (void)(x)
+#endif
 #ifndef INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP
 #define INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP 1
 #endif
@@ -382,7 +390,8 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       if (in_range) {
 #pragma unroll
         for (int k = 0; k < K; ++k) {
-          const uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + col0;
+          uint64_t off = (((uint64_t)p * K + k) * a.row_count + row) * a.N1 + col0;
+          INFLX_KEEP_SCALAR(off);  // (see below: keeps the row base in scalar registers)
           store_scalar<OP>(a.out, off, tid, o[k]);
         }
       }
@@ -397,7 +406,12 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      inflx_d2* dst = reinterpret_cast<inflx_d2*>(a.out + (((uint64_t)p * a.row_count + row) * a.N1 + col0) * 6);  // the workgroup's 12 KiB of this row
+      // The row offset is made opaque to the loop optimiser: strength reduction would turn "scalar base(row) + thread offset"
+      // back into per-lane pointers that it advances every row (it did, in the hot loop only: the redo loop's rows are not an
+      // arithmetic sequence).  (The offset, not the pointer: a pointer that went through an asm loses its address space.)
+      uint64_t row_off = (((uint64_t)p * a.row_count + row) * a.N1 + col0) * 6;
+      INFLX_KEEP_SCALAR(row_off);
+      inflx_d2* dst = reinterpret_cast<inflx_d2*>(a.out + row_off);  // the workgroup's 12 KiB of this row
       const inflx_d2* units = reinterpret_cast<const inflx_d2*>(tb);
       // all three LDS reads are issued before the first (predicated) store: one LDS round trip per row
       // instead of three (left alone, the compiler sinks every read into its store's branch)
@@ -417,7 +431,9 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     } else {
       if (in_range) {
-        double* dst = a.out + (((uint64_t)p * a.row_count + row) * a.N1 + col0) * K;
+        uint64_t row_off = (((uint64_t)p * a.row_count + row) * a.N1 + col0) * K;
+        INFLX_KEEP_SCALAR(row_off);
+        double* dst = a.out + row_off;
 #pragma unroll
         for (int k = 0; k < K; ++k) store_d1(dst + (tid * (unsigned)K + k), o[k]);
       }
