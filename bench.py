@@ -42,6 +42,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full rate (78.6 TFLOP/s = 2 flop x this)
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
+# parameter-row sweeps (8192^2 each, ~0.45 ms) run untimed before the warm-up steps so that the clocks have settled: 64 = 29 ms
+SETTLE_ROW_SWEEPS = 64
 PROFILE_ROUNDS = ("03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json: newest first
 
 
@@ -264,6 +266,7 @@ def main():
     ap.add_argument("--model", default="hyperbolic")
     ap.add_argument("--grid", dest="n", type=int, default=8192, help="grid points per axis")
     ap.add_argument("--rows-per-gpu", type=int, default=None, help="parameter rows per GPU and step (default: 1 at N = 1, 64 at N > 1 = BASELINE configs[4] on 8 GPUs)")
+    ap.add_argument("--no-settle", dest="settle", action="store_false", help="skip the untimed clock-settling sweeps before the warm-up steps")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the secondary workloads and the end-to-end call")
     opt = ap.parse_args()
@@ -349,6 +352,14 @@ def main():
     def step():
         lib.sweep_device(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream)
 
+    # Before the W warm-up steps: untimed sweeps of the same workload until the shader / memory clocks have settled.  The
+    # first ~25 launches (~11 ms) of a store stream after idle run up to 8 % slow while the clock governor finds its level
+    # (kernel trace in profiles/r03_experiments.txt section 15: 437 -> 471 -> 433 us); with W = 3 the timed region would
+    # sit entirely inside that transient (0.478 ms/step instead of 0.447).  Same call, same arguments, results discarded
+    # like any warm-up step; the timed region below is still exactly K steps of the full workload.
+    settle_steps = max(1, -(-SETTLE_ROW_SWEEPS // rows_per_gpu)) if opt.settle else 0
+    for _ in range(settle_steps):
+        step()
     for _ in range(opt.warmup):
         step()
     torch.cuda.synchronize()
@@ -443,6 +454,7 @@ def main():
                     f"{rows_per_gpu} rows per GPU swept by ONE call per step, extent {list(spec.extent)}, complete_analysis (6 f64/point, AoS), "
                     f"{rows_per_gpu * N0 * N1 * BYTES_PER_POINT / 1e9:.1f} GB of results resident per GPU"
                 ),
+                "untimed_sweeps_before_warmup": settle_steps * rows_per_gpu,  # clock settling, see the comment at the warm-up loop
                 "parameter_rows_per_gpu": rows_per_gpu,
                 "parameter_rows_total": total_rows,
                 "baseline_config": "configs[1]" if total_rows == 1 else ("configs[4]" if (total_rows, N0) == (512, 8192) else f"configs[4] axis, first {total_rows} of 512 rows"),

@@ -37,6 +37,7 @@ def test_single_gpu_line():
     assert roof["per_rank"][0]["rank"] == 0 and abs(roof["per_rank"][0]["kernel_ms"] - roof["kernel_ms"]) < 1e-9
     assert line["rccl_ranks"] == 0 and line["ranks"] == 1
     assert line["config"]["parameter_rows_per_gpu"] == 1 and line["config"]["baseline_config"] == "configs[1]"
+    assert line["config"]["untimed_sweeps_before_warmup"] == 64  # clock settling, disclosed on the line
     # BASELINE configs[2] and [3] and the PCIe-inclusive front-end call ride on the same line (never part of `value`)
     sec = {rec["workload"].split(",")[0]: rec for rec in line["secondary"]}
     assert all("error" not in rec for rec in line["secondary"]), line["secondary"]
@@ -76,6 +77,7 @@ def test_two_rank_rehearsal(form):
     # every rank's rows are counted: value = ranks * rows per rank * points * steps / max-over-ranks time
     assert abs(line["value"] - 2 * rows * 2048 * 2048 * 5 / (line["ms_per_step"] * 5e-3)) / line["value"] < 1e-9
     assert line["config"]["parameter_rows_per_gpu"] == rows and line["config"]["parameter_rows_total"] == 2 * rows
+    assert line["config"]["untimed_sweeps_before_warmup"] == (66 if rows == 3 else 64)  # whole calls: ceil(64 / rows) * rows
     assert "configs[4]" in line["config"]["baseline_config"] and "linspace(0.2, 2.0, 512)" in line["config"]["workload"]
     # the summary of all parameter rows was combined across ranks (epsilon_V is finite everywhere)
     assert line["summary_sweep"]["non_nan"][1] == 2 * rows * 2048 * 2048
