@@ -9,6 +9,12 @@
  * `inflx_last_error()` returns a thread-local message.  The mapping to the Python exception
  * classes the reference raises (src/err.rs:63-74) is given with each status.
  *
+ * Threads: calls on different handles may run concurrently; calls on the SAME handle are serialised
+ * by the library (a per-handle lock held for the call) -- the reference gets the same effect from
+ * the GIL, which it holds for a whole sweep (src/anguelova.rs:458-465) and which a ctypes / cgo /
+ * FFI binding of this library does not.  Closing a handle that another thread still uses remains
+ * the caller's error.
+ *
  * A "model artefact" is the per-model gfx950 code object written by inflatox_amd.Compiler -- the
  * counterpart of the per-model dylib the reference compiles with zig cc
  * (python/inflatox/compiler.py:568-598) and opens with libloading (src/dylib.rs:67-161).

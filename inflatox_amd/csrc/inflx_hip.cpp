@@ -20,6 +20,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <future>
 #include <random>
 #include <string>
@@ -163,7 +164,16 @@ void prefault_range(char* begin, size_t bytes) {
 }
 }  // namespace
 
+#define INFLX_SERIALISE(m) \
+  std::unique_lock<std::recursive_mutex> inflx_call_lock_; \
+  if (m) inflx_call_lock_ = std::unique_lock<std::recursive_mutex>((m)->mu)
+
 struct inflx_model {
+  // Every entry point that works on a handle holds this lock for the call: a handle owns streams, staging buffers, the
+  // parameter-slot ring and the double-buffered tables, none of which two calls may use at once.  (The reference holds the
+  // GIL for a whole sweep; ctypes releases it, so two Python threads can arrive here together.)  Recursive: the timed and
+  // validating entry points call the plain ones.  Different handles never wait for each other.
+  std::recursive_mutex mu;
   int device = 0;
   hipModule_t module = nullptr;
   hipStream_t stream = nullptr;
@@ -853,6 +863,7 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
 
 void inflx_close(inflx_model* m) {
   if (!m) return;
+  { std::lock_guard<std::recursive_mutex> last_call_has_returned(m->mu); }  // (closing a handle another thread still uses remains the caller's error)
   (void)hipSetDevice(m->device);
   if (m->stream) (void)hipStreamSynchronize(m->stream);
   if (m->side) (void)hipStreamSynchronize(m->side);
@@ -922,6 +933,7 @@ int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t r
 
 int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes, const double* ss,
                              size_t N0, size_t N1, size_t row_begin, size_t row_count, void* stream, inflx_summary* summary) {
+  INFLX_SERIALISE(m);
   const int op = INFLX_OP_COMPLETE;
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
@@ -958,6 +970,7 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
 }
 
 int inflx_synchronize(inflx_model* m) {
+  INFLX_SERIALISE(m);
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->side));
@@ -967,6 +980,7 @@ int inflx_synchronize(inflx_model* m) {
 
 int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                        const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream) {
+  INFLX_SERIALISE(m);
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
   if (!d_out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
@@ -989,6 +1003,7 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                              const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream,
                              int repeats, int dominant_only, float* ms_per_launch) {
+  INFLX_SERIALISE(m);
   if (repeats <= 0 || !ms_per_launch) return fail(INFLX_ERR_ARG, "repeats must be positive and ms_per_launch non-NULL");
   // first call validates everything and uploads the parameters
   int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
@@ -1013,6 +1028,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
 }
 
 int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const double* x, size_t n, double* out) {
+  INFLX_SERIALISE(m);
   int rc = validate(m, INFLX_OP_RAW, p, 1, n_p);
   if (rc) return rc;
   if (n == 0) return INFLX_OK;
@@ -1040,6 +1056,7 @@ int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const dou
 }
 
 int inflx_ops_on_values(inflx_model* m, const double* values, size_t n, double* out, int ieee_only) {
+  INFLX_SERIALISE(m);
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   if (n == 0) return INFLX_OK;
   if (!values || !out) return fail(INFLX_ERR_ARG, "values / output pointer is NULL");
@@ -1066,6 +1083,7 @@ int inflx_ops_on_values(inflx_model* m, const double* values, size_t n, double* 
 }
 
 int inflx_validate_basis_at_random(inflx_model* m, uint64_t seed) {
+  INFLX_SERIALISE(m);
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   // src/lib.rs:142-162: one random parameter vector in [-10, 10), 100 random points in [-1, 1)^2
   const size_t num_points = 100;
@@ -1086,6 +1104,7 @@ int inflx_validate_basis_at_random(inflx_model* m, uint64_t seed) {
 
 int inflx_validate_basis_on_domain(inflx_model* m, const uint32_t* num_points, size_t n_axes, const double* p, size_t n_p,
                                    const double* ss, double accuracy) {
+  INFLX_SERIALISE(m);
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   if (!num_points || !ss) return fail(INFLX_ERR_ARG, "num_points / start_stop array is NULL");
   say("Validating basis orthonormality on specified domain. This may take a while...");
@@ -1124,6 +1143,7 @@ namespace {
 // host-result sweep for every operation; `out` holds kOpBytes[op] bytes per grid point
 int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
                     size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy) {
+  INFLX_SERIALISE(m);
   char* const out = static_cast<char*>(out_v);
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
@@ -1308,6 +1328,7 @@ int inflx_epsilon_v_only(inflx_model* m, const double* p, size_t n_p, double* ou
 
 int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_p, const double* x, size_t n, double* out,
                               int progress, size_t /*threads*/) {
+  INFLX_SERIALISE(m);
   int rc = validate(m, op, p, 1, n_p);
   if (rc) return rc;
   if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has no on-trajectory variant in the reference");

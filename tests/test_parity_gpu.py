@@ -944,6 +944,50 @@ def test_concurrent_sweeps_from_two_threads(gpu_lib):
 
 
 @pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_one_handle_shared_by_threads(name, gpu_lib):
+    """Calls on ONE handle from several threads (the reference serialises them with the GIL, src/anguelova.rs:458-465 runs
+    under it; ctypes releases it): the library holds a per-handle lock for the call, so every thread gets the results of
+    its own parameter row -- host sweeps, device sweeps, trajectories and summaries mixed, row-broadcast and tile path."""
+    import threading
+
+    import torch
+
+    spec, art, lib = devlib(name, gpu_lib)
+    ss = np.array(spec.extent).reshape(2, 2)
+    n0, n1 = 96, 320
+    rows = [np.array(spec.args) * (1.0 + 0.01 * k) for k in range(4)]
+    single = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    want = [single.sweep_host(gpu_lib.OP_COMPLETE, r, ss, n0, n1) for r in rows]
+    pts = np.column_stack([np.linspace(spec.extent[0], spec.extent[1], 50, endpoint=False), np.linspace(spec.extent[2], spec.extent[3], 50, endpoint=False)])
+    want_traj = [single.sweep_on_trajectory(gpu_lib.OP_COMPLETE, r, pts) for r in rows]
+    errors = []
+
+    def work(k):
+        try:
+            stream = torch.cuda.Stream(device="cuda:0")
+            out = torch.empty((n0, n1, 6), dtype=torch.float64, device="cuda:0")
+            for it in range(12):
+                got = lib.sweep_host(gpu_lib.OP_COMPLETE, rows[k], ss, n0, n1)
+                assert np.array_equal(got, want[k], equal_nan=True), ("host", k, it)
+                lib.sweep_device(gpu_lib.OP_COMPLETE, rows[k], out.data_ptr(), out.numel() * 8, ss, n0, n1, stream=stream.cuda_stream)
+                stream.synchronize()
+                assert np.array_equal(out.cpu().numpy(), want[k], equal_nan=True), ("device", k, it)
+                assert np.array_equal(lib.sweep_on_trajectory(gpu_lib.OP_COMPLETE, rows[k], pts), want_traj[k], equal_nan=True), ("trajectory", k, it)
+                summary = lib.sweep_stats(rows[k], ss, n0, n1)
+                fin = ~np.isnan(want[k][..., 1])
+                assert summary["count"][1] == fin.sum() and summary["max"][1] == want[k][..., 1][fin].max(), ("summary", k, it)
+        except Exception as exc:  # noqa: BLE001
+            errors.append((k, repr(exc)))
+
+    threads = [threading.Thread(target=work, args=(k,)) for k in range(len(rows))]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
 def test_empty_inputs_are_no_ops(name, gpu_lib):
     """Zero-size grids and trajectories: the reference's loops simply do not run (an (0, N, 6) array is a valid
     C-contiguous numpy array); no launch, no error, empty results of the right shape."""
