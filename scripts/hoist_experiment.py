@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): tile-kernel time of the hoisted-reciprocal division against the default.
-usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, nohoist, regroup, share, nosqrt, trust (-DINFLX_DIVH_TRUST: accept every quotient),
+usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, nohoist, regroup, share, nosqrt, tanN (tan_shortcut=N), trust (-DINFLX_DIVH_TRUST: accept every quotient),
 wN (N waves/SIMD: -DINFLX_MIN_WAVES=N), inner (grid away from the first row/column), DNAME=value (any -D switch of the kernel sources, e.g.
 DINFLX_HORNER_MODE=0, DINFLX_EXPERIMENT_IEEE_EPILOGUE=1, DINFLX_TAN_SHORTCUT_MAX=16)"""
 import os
@@ -50,6 +50,9 @@ for case in cases * rounds:
         kw["regroup"] = True
     if "share" in fl:
         kw["share_reciprocals"] = True
+    for f in fl:
+        if f.startswith("tan") and f[3:].isdigit():  # tanN: Compiler(tan_shortcut=N)
+            kw["tan_shortcut"] = int(f[3:])
     if "nosqrt" in fl:  # the point stage's square roots as the compiler spells them
         kw["quick_sqrt"] = False
     art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, hoist_reciprocals=hoist, **kw).compile()
