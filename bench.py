@@ -215,6 +215,57 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
     return out
 
 
+def next_rows(_native, workloads, torch, np, device, stream):
+    """SURVEY.md section 8(f), the rows either side of the headline path, each timed on this GPU (never part of `value`):
+    f1 the single-quantity sweeps (8 B/point: row-broadcast planes stream for the hyperbolic model, tile kernels for the doc
+    model), f2 an on-trajectory call (host points in, host results out: latency, not bandwidth), f3 the raw-values sweep
+    behind calc_V_array / calc_H_array (5 SoA planes).  Kernel-side figures by HIP events on the launch stream
+    (sweep_device_timed, best of 3 batches of 20), host-side calls by wall clock (best of 5)."""
+    import time
+
+    out = []
+
+    def device_sweep(row, model, op, n, layout, what, width):
+        try:
+            spec, art = workloads.artifact_for(model)
+            lib = _native.InflatoxDevLib(art.shared_object_path, device=device)
+            buf = torch.empty((n * n * width,), dtype=torch.float64, device=f"cuda:{device}")
+            ms = min(lib.sweep_device_timed(op, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, layout=layout, stream=stream, repeats=20) for _ in range(3))
+            pps = n * n / (ms * 1e-3)
+            plan = lib.sweep_plan(op, 1, n, n, layout=layout)
+            out.append({"row": row, "workload": f"{model} {n}x{n}, {what}", "path": plan.get("path"), "ms": ms, "points_per_s": pps,
+                        "bytes_per_point": 8 * width, "GBps": 8 * width * pps / 1e9, "hbm_frac": 8 * width * pps / 1e9 / HBM_PEAK_GBPS,
+                        "timing": "HIP events around 20 back-to-back sweeps, best of 3 batches", "code_object": code_object_id(art)})
+            del buf
+        except Exception as exc:  # noqa: BLE001 -- a side figure must never cost the benchmark line
+            out.append({"row": row, "workload": f"{model} {n}x{n}, {what}", "error": str(exc)[:300]})
+
+    for op, name in ((_native.OP_CONSISTENCY, "consistency_only"), (_native.OP_EPSILON_V, "epsilon_v_only"), (_native.OP_RAPIDTURN, "consistency_rapidturn_only")):
+        device_sweep("f1", "hyperbolic", op, 8192, _native.LAYOUT_AOS, f"{name} (src/anguelova.rs:138-163), one f64 per point", 1)
+    device_sweep("f1", "doc", _native.OP_CONSISTENCY, 4096, _native.LAYOUT_AOS, "consistency_only, one f64 per point", 1)
+    device_sweep("f1", "doc", _native.OP_EPSILON_V, 4096, _native.LAYOUT_AOS, "epsilon_v_only, one f64 per point", 1)
+    device_sweep("f3", "doc", _native.OP_RAW, 4096, _native.LAYOUT_SOA, "V, v00, v10, v11, |dV|^2 as five planes (what calc_V_array / calc_H_array read)", 5)
+    torch.cuda.empty_cache()
+    try:  # f2: the on-trajectory call of the reference's trajectory fixtures' size, and a long one
+        spec, art = workloads.artifact_for("doc")
+        lib = _native.InflatoxDevLib(art.shared_object_path, device=device)
+        rng = np.random.default_rng(7)
+        x0a, x0b, x1a, x1b = spec.extent
+        for npts in (500, 1_000_000):
+            pts = np.column_stack([rng.uniform(x0a, x0b, npts), rng.uniform(x1a, x1b, npts)])
+            lib.sweep_on_trajectory(_native.OP_COMPLETE, spec.args, pts)
+            best = float("inf")
+            for _ in range(5):
+                t0 = time.perf_counter()
+                lib.sweep_on_trajectory(_native.OP_COMPLETE, spec.args, pts)
+                best = min(best, time.perf_counter() - t0)
+            out.append({"row": "f2", "workload": f"doc, complete_analysis_ot on {npts} points (host points in, host results out)", "ms": best * 1e3, "points_per_s": npts / best,
+                        "timing": "wall clock of the call, best of 5"})
+    except Exception as exc:  # noqa: BLE001
+        out.append({"row": "f2", "error": str(exc)[:300]})
+    return out
+
+
 def end_to_end(workloads, np, model: str, n: int, device: int):
     """The front-end call a user of the reference makes, GeneralisedAL.complete_analysis -> six numpy arrays on the host
     (device sweep + PCIe copy), and the two opt-in forms that avoid the copy.  `cold` = the first call of the process:
@@ -491,6 +542,7 @@ def main():
             del out
             torch.cuda.empty_cache()
             line["secondary"] = secondary_workloads(_native, workloads, torch, np, local_rank, stream)
+            line["next_rows"] = next_rows(_native, workloads, torch, np, local_rank, stream)
             try:
                 line["end_to_end"] = end_to_end(workloads, np, opt.model, opt.n, local_rank)
             except Exception as exc:  # noqa: BLE001

@@ -44,6 +44,11 @@ def test_single_gpu_line():
     assert sec["D5-brane model"]["points_per_s"] > 1e9 and sec["EGNO supergravity model"]["points_per_s"] > 1e9
     assert "x 32 parameter rows" in sec["D5-brane model"]["workload"]
     assert line["end_to_end"]["points_per_s"] > 1e8
+    # the single-quantity sweeps, an on-trajectory call and the raw-values planes are measured on the same line
+    rows = line["next_rows"]
+    assert all("error" not in rec for rec in rows), rows
+    assert {rec["row"] for rec in rows} == {"f1", "f2", "f3"} and all(rec["points_per_s"] > 0 for rec in rows)
+    assert {rec["path"] for rec in rows if rec["row"] == "f1"} == {"row_stream", "tile"}
 
 
 def _free_port():
