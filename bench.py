@@ -443,7 +443,11 @@ def main():
     # the dominant kernel on its own: the store stream of ONE parameter row of this rank's block (its launch is the
     # same for every row; the timing-only mode needs the rows to fit one table batch)
     one_row = args[:1]
-    ms_kernel = lib.sweep_device_timed(_native.OP_COMPLETE, one_row, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(5, opt.steps), dominant_only=row_path)
+    ms_kernel_isolated = lib.sweep_device_timed(_native.OP_COMPLETE, one_row, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(5, opt.steps), dominant_only=row_path)
+    # ... and where the roofline prices it: INSIDE the step, exactly as the timed region enqueues it (all rows of the block, the
+    # per-row evaluation overlapping on the side stream, the cross-stream waits in place), from HIP event pairs recorded on the
+    # launch stream around every launch of the dominant kernel; per parameter row
+    ms_kernel = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(2, min(opt.steps, 40 // rows_per_gpu)), in_pipeline=True) / rows_per_gpu
     # ... and the whole step (all rows of the block, every launch of the call), per parameter row
     ms_sweep = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(2, min(opt.steps, 40 // rows_per_gpu))) / rows_per_gpu
     points = N0 * N1
@@ -526,6 +530,8 @@ def main():
                 "code_object": cid,
                 "kernel": kernel,
                 "kernel_ms": ms_kernel,
+                "kernel_timing": "HIP event pairs on the launch stream around every launch of the dominant kernel inside full steps (per parameter row); kernel_ms_isolated: the same kernel relaunched back to back on its own",
+                "kernel_ms_isolated": ms_kernel_isolated,
                 "sweep_ms": ms_sweep,  # whole step / parameter rows per step
                 "call_GBps": BYTES_PER_POINT * points / (ms_sweep * 1e-3) / 1e9,
                 "timed_region_ms_per_step_hip_events": step_ms_events,

@@ -174,7 +174,10 @@ int inflx_sweep_plan(const inflx_model* model, int op, size_t P, size_t N1, size
 /* As inflx_sweep_device, `repeats` times back to back between two HIP events recorded on the
  * launch stream; returns the mean duration of one sweep in milliseconds (synchronises).  A sweep of a
  * model whose values do not depend on x[1] is two launches (per-row evaluation, then the store stream);
- * with `dominant_only` != 0 only the dominant one -- the store stream -- is repeated and timed. */
+ * with `dominant_only` == 1 only the dominant one -- the store stream -- is repeated and timed; with
+ * `dominant_only` == 2 the full sweeps are enqueued as in mode 0 and the value returned is the time spent
+ * between event pairs recorded around every launch of the dominant kernel, per sweep: its duration inside
+ * the pipeline (side-stream evaluation overlapping, cross-stream waits in place). */
 int inflx_sweep_device_timed(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
                              size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
                              size_t row_count, int layout, void* stream, int repeats, int dominant_only,

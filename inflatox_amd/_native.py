@@ -337,9 +337,10 @@ class InflatoxDevLib:
             )
         )
 
-    def sweep_device_timed(self, op, p, d_out_ptr, d_out_bytes, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, repeats: int = 10, dominant_only: bool = False) -> float:
+    def sweep_device_timed(self, op, p, d_out_ptr, d_out_bytes, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, repeats: int = 10, dominant_only: bool = False, in_pipeline: bool = False) -> float:
         """Mean duration (ms) of one sweep over ``repeats`` repetitions, HIP events on the launch stream;
-        ``dominant_only`` times just the dominant kernel of a multi-launch sweep."""
+        ``dominant_only`` times just the dominant kernel of a multi-launch sweep, relaunched on its own; ``in_pipeline``
+        enqueues the full sweeps and returns the dominant kernel's time per sweep from event pairs around its launches."""
         p2 = _f64(p, "p")
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
@@ -347,7 +348,7 @@ class InflatoxDevLib:
         ms = C.c_float(0.0)
         _check(
             self._lib.inflx_sweep_device_timed(
-                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, int(bool(dominant_only)), C.byref(ms)
+                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, 2 if in_pipeline else int(bool(dominant_only)), C.byref(ms)
             )
         )
         return float(ms.value)

@@ -211,6 +211,10 @@ struct inflx_model {
   hipEvent_t table_free[2] = {nullptr, nullptr};   // the store stream that last read buffer b finished
   bool table_used[2] = {false, false};
   unsigned table_turn = 0;
+  // inflx_sweep_device_timed(..., dominant_only = 2): event pairs recorded around every dominant-kernel launch of the sweeps it
+  // enqueues -- the kernel's duration inside the full pipeline (side-stream evaluation overlapping, cross-stream waits in place)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>>* probe = nullptr;
+  size_t probe_used = 0;
   InflxKernelInfo info = {};
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
@@ -398,6 +402,16 @@ RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P
   return r;
 }
 
+// (in-pipeline timing of the dominant kernel, see inflx_model::probe) -- no-ops unless a probe is armed and has pairs left
+hipError_t probe_begin(inflx_model* m, hipStream_t s) {
+  if (!m->probe || m->probe_used >= m->probe->size()) return hipSuccess;
+  return hipEventRecord((*m->probe)[m->probe_used].first, s);
+}
+hipError_t probe_end(inflx_model* m, hipStream_t s) {
+  if (!m->probe || m->probe_used >= m->probe->size()) return hipSuccess;
+  return hipEventRecord((*m->probe)[m->probe_used++].second, s);
+}
+
 // ---- the four ways a sweep is enqueued; `a` arrives with the grid geometry filled in (launch_grid) -------------------
 
 // Row-broadcast path: per-row values into the row table on the side stream, then the broadcast store stream on `s`
@@ -441,8 +455,10 @@ int launch_row_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
         const size_t nr = std::min<size_t>(65535, row_count - r0);
+        HIP_TRY(probe_begin(m, s));
         HIP_TRY(hipModuleLaunchKernel(aos6 ? m->rowstream6 : m->rowstream_planes, (unsigned)cpr, (unsigned)nr,
                                       (unsigned)(aos6 ? pb : pb * K), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+        HIP_TRY(probe_end(m, s));
       }
       HIP_TRY(hipEventRecord(m->table_free[b], s));
       m->table_used[b] = true;
@@ -490,7 +506,9 @@ int launch_col_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
         const size_t nr = std::min<size_t>(65535, row_count - r0);
+        HIP_TRY(probe_begin(m, s));
         HIP_TRY(hipModuleLaunchKernel(m->colstream, (unsigned)cpr, (unsigned)nr, (unsigned)(pb * images_per_p), m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+        HIP_TRY(probe_end(m, s));
       }
       HIP_TRY(hipEventRecord(m->table_free[b], s));
       m->table_used[b] = true;
@@ -566,7 +584,9 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
       // ... and the tile kernel on the caller's stream behind them
       HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
       const size_t gy = (slab + m->info.tile_rows - 1) / m->info.tile_rows;
+      HIP_TRY(probe_begin(m, s));
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
+      HIP_TRY(probe_end(m, s));
       HIP_TRY(hipEventRecord(m->stage_free[b], s));
       m->stage_used[b] = true;
     }
@@ -1012,17 +1032,48 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   hipStream_t reader = last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side;
   const double* d_params = m->pslot[m->pcur].dev;  // what the call above uploaded (or found in place)
   HIP_TRY(hipStreamSynchronize(s));
+  // dominant_only == 2: the full sweeps, with an event pair around every dominant-kernel launch (at most 64 per sweep)
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
+  struct Disarm {
+    inflx_model* m;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>>& pairs;
+    ~Disarm() {
+      m->probe = nullptr;
+      for (auto& pr : pairs) {
+        if (pr.first) (void)hipEventDestroy(pr.first);
+        if (pr.second) (void)hipEventDestroy(pr.second);
+      }
+    }
+  } disarm{m, pairs};
+  if (dominant_only == 2) {
+    pairs.assign((size_t)repeats * 64, {nullptr, nullptr});
+    for (auto& pr : pairs) {
+      HIP_TRY(hipEventCreate(&pr.first));
+      HIP_TRY(hipEventCreate(&pr.second));
+    }
+    m->probe = &pairs;
+    m->probe_used = 0;
+  }
   HIP_TRY(hipEventRecord(m->t0, s));
   for (int k = 0; k < repeats; ++k) {
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s,
-                     dominant_only ? 2 : 0);
+                     dominant_only == 1 ? 2 : 0);
     if (rc) return release_params_after(m, reader, rc);
   }
   HIP_TRY(hipEventRecord(m->t1, s));
   if ((rc = release_params(m, reader))) return rc;
   HIP_TRY(hipEventSynchronize(m->t1));
   float ms = 0.f;
-  HIP_TRY(hipEventElapsedTime(&ms, m->t0, m->t1));
+  if (dominant_only == 2) {
+    if (m->probe_used == 0) return fail(INFLX_ERR_ARG, "in-pipeline timing: this sweep shape has no probed kernel");
+    for (size_t k = 0; k < m->probe_used; ++k) {
+      float one = 0.f;
+      HIP_TRY(hipEventElapsedTime(&one, pairs[k].first, pairs[k].second));
+      ms += one;
+    }
+  } else {
+    HIP_TRY(hipEventElapsedTime(&ms, m->t0, m->t1));
+  }
   *ms_per_launch = ms / (float)repeats;
   return INFLX_OK;
 }

@@ -36,6 +36,8 @@ def test_single_gpu_line():
     assert "workload" in line["config"] and "model" not in line["config"]
     assert roof["per_rank"][0]["rank"] == 0 and abs(roof["per_rank"][0]["kernel_ms"] - roof["kernel_ms"]) < 1e-9
     assert line["rccl_ranks"] == 0 and line["ranks"] == 1
+    # the roofline prices the dominant kernel as it runs inside the steps; the isolated relaunch is reported beside it
+    assert 0.5 * roof["kernel_ms_isolated"] < roof["kernel_ms"] < 2.0 * roof["kernel_ms_isolated"] and roof["kernel_ms"] <= 1.05 * roof["timed_region_ms_per_step_hip_events"]
     assert line["config"]["parameter_rows_per_gpu"] == 1 and line["config"]["baseline_config"] == "configs[1]"
     assert line["config"]["untimed_sweeps_before_warmup"] == 64  # clock settling, disclosed on the line
     # BASELINE configs[2] and [3] and the PCIe-inclusive front-end call ride on the same line (never part of `value`)

@@ -232,6 +232,12 @@ def test_dominant_only_timing_refuses_several_batches(hyp, gpu_lib):
     ms = lib.sweep_device_timed(gpu_lib.OP_COMPLETE, rows[:4], out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream, repeats=2, dominant_only=True)
     assert ms > 0
     check_block(out[:4], rows[:4], spec.extent, n0, "after dominant-only timing")
+    # the in-pipeline mode times the store streams inside full sweeps -- several table batches are fine there (5 rows = 4 + 1):
+    # it lies between nothing and the whole sweep, and the results are those of an ordinary sweep
+    whole = lib.sweep_device_timed(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream, repeats=2)
+    inside = lib.sweep_device_timed(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n0, n1, stream=torch.cuda.current_stream().cuda_stream, repeats=2, in_pipeline=True)
+    assert 0.5 * whole < inside <= 1.02 * whole, (inside, whole)
+    check_block(out, rows, spec.extent, n0, "after in-pipeline timing")
 
 
 @pytest.mark.parametrize("name", ["hyperbolic", "doc"])
