@@ -215,6 +215,7 @@ struct inflx_model {
   // enqueues -- the kernel's duration inside the full pipeline (side-stream evaluation overlapping, cross-stream waits in place)
   std::vector<std::pair<hipEvent_t, hipEvent_t>>* probe = nullptr;
   size_t probe_used = 0;
+  bool probe_overflow = false;  // more dominant-kernel launches than event pairs: the timing would be partial
   InflxKernelInfo info = {};
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
@@ -404,7 +405,11 @@ RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P
 
 // (in-pipeline timing of the dominant kernel, see inflx_model::probe) -- no-ops unless a probe is armed and has pairs left
 hipError_t probe_begin(inflx_model* m, hipStream_t s) {
-  if (!m->probe || m->probe_used >= m->probe->size()) return hipSuccess;
+  if (!m->probe) return hipSuccess;
+  if (m->probe_used >= m->probe->size()) {
+    m->probe_overflow = true;
+    return hipSuccess;
+  }
   return hipEventRecord((*m->probe)[m->probe_used].first, s);
 }
 hipError_t probe_end(inflx_model* m, hipStream_t s) {
@@ -1053,6 +1058,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
     }
     m->probe = &pairs;
     m->probe_used = 0;
+    m->probe_overflow = false;
   }
   HIP_TRY(hipEventRecord(m->t0, s));
   for (int k = 0; k < repeats; ++k) {
@@ -1066,6 +1072,7 @@ int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, 
   float ms = 0.f;
   if (dominant_only == 2) {
     if (m->probe_used == 0) return fail(INFLX_ERR_ARG, "in-pipeline timing: this sweep shape has no probed kernel");
+    if (m->probe_overflow) return fail(INFLX_ERR_ARG, "in-pipeline timing: more than 64 launches of the dominant kernel per sweep (use fewer parameter rows per call)");
     for (size_t k = 0; k < m->probe_used; ++k) {
       float one = 0.f;
       HIP_TRY(hipEventElapsedTime(&one, pairs[k].first, pairs[k].second));
