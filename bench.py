@@ -106,6 +106,16 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
         t0 = time.perf_counter()
         om.grid_sweep(oracle.OP.COMPLETE, args, extent, n, n, threads=cores)
         best = min(best, time.perf_counter() - t0)
+    # BASELINE configs[0] as written: the 256 x 256 grid of the reference's own CPU-runnable case, all threads and one thread
+    # (at 65 536 points the thread start-up is a visible share of a pass: best of 20)
+    def at_256(threads):
+        t_best = float("inf")
+        for _ in range(20):
+            t0 = time.perf_counter()
+            om.grid_sweep(oracle.OP.COMPLETE, args, extent, 256, 256, threads=threads)
+            t_best = min(t_best, time.perf_counter() - t0)
+        return {"ms": t_best * 1e3, "points_per_s": 256 * 256 / t_best, "threads": threads}
+
     return {
         "value": n * n / best,
         "unit": "grid-points/s",
@@ -113,6 +123,7 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
         "kind": "port",
         "sample": f"{model_name} {n}x{n} grid over the same extent (per-point cost does not depend on grid size), best of 3 passes, "
         f"{cores} threads ({os.cpu_count()} logical CPUs on the host), gcc -O3 -march=native model object + C restatement of the Rust sweep",
+        "configs0_256x256": {"what": "BASELINE configs[0]: the same model on its 256x256 grid, best of 20 passes", "all_threads": at_256(cores), "one_thread": at_256(1)},
     }
 
 

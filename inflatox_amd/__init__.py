@@ -5,7 +5,7 @@ Public surface mirrors the reference package (python/inflatox/__init__.py:20-40)
 """
 
 from .compiler import CompilationArtifact, Compiler
-from .symbolic import InflationModel, InflationModelBuilder
+from .symbolic import InflationModel, InflationModelBuilder, SymbolicCalculation
 from .version import __version__
 
 __all__ = [
@@ -13,6 +13,7 @@ __all__ = [
     "Compiler",
     "InflationModel",
     "InflationModelBuilder",
+    "SymbolicCalculation",
     "consistency_conditions",
     "__version__",
 ]

@@ -58,7 +58,12 @@ class HostModel:
         cxx = host_compiler()
         if cxx is None:
             raise RuntimeError("no host C++ compiler for the conditioning instrument")
-        tag = hashlib.sha256((header_text + str(long_double) + cxx).encode()).hexdigest()[:20]
+        # the shared object is a function of the header, the switch, the compiler AND the sources it includes
+        key = hashlib.sha256((header_text + str(long_double) + cxx).encode())
+        for dep in ("inflx_host_instrument.cpp", "inflx_ops.h", "inflx_device_math.h", "inflx_sf.h", "inflx_sf_tables.h"):
+            with open(os.path.join(_CSRC, dep), "rb") as fh:
+                key.update(fh.read())
+        tag = key.hexdigest()[:20]
         d = _private_build_dir()
         hdr, so = os.path.join(d, f"{tag}.h"), os.path.join(d, f"{tag}.so")
         if not os.path.exists(so):

@@ -299,13 +299,14 @@ class Compiler:
       second copy of the point stage plus the ``ok`` bookkeeping for models that would not have them otherwise: measured
       4096^2, doc 0.216 -> 0.218 ms, angular 0.256 -> 0.261, EGNO 0.403 -> 0.416 (148 -> 168 VGPRs), D5 0.446 -> 0.438.  ``None``
       therefore switches it on exactly where the quick point stage exists anyway (hoisted reciprocals on: D5).
-    * ``tan_shortcut`` (default 16; 0 = off; ``None`` reads the environment variable ``INFLX_TAN_SHORTCUT``, else the default): the epilogue's
-      ``tan(atan(t))``, t = |v10/v00| (src/anguelova.rs:128,132), is taken as ``t`` itself wherever ``t <= tan_shortcut``.
-      The reference's two libm calls return t(1 + e) with |e| <~ (t + 1/t)*2^-53, so the results differ from those of
-      ``tan_shortcut=0`` by at most ~(tan_shortcut + 1)*2^-53 relative on ``tan(delta)`` -- far inside the 1e-10 bar, and closer to the
-      exact value than the reference itself -- but they are not OCML's tan of OCML's atan bit for bit (``tan_shortcut=0``
-      gives that); a wavefront
-      all of whose points qualify skips the ~55 instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
+    * ``tan_shortcut`` (default ``None``: 0 = off for every build in the reference's arithmetic, ``TUNED_TAN_SHORTCUT`` = 16 together
+      with ``regroup="auto"``, the profile-guided build): the epilogue's ``tan(atan(t))``, t = |v10/v00|
+      (src/anguelova.rs:128,132), is taken as ``t`` itself wherever ``t <= tan_shortcut``.  With 0 the kernels evaluate OCML's
+      tan of OCML's atan, operation for operation -- the counterpart of the reference's two libm calls.  Those return
+      t(1 + e) with |e| <~ (t + 1/t)*2^-53, so a shortcut bound T moves ``tan(delta)`` by at most ~(T + 1)*2^-53 relative --
+      far inside the 1e-10 bar, and towards the exact value -- but the results are then no longer the composition bit for
+      bit, which is why the default build does not take it; a wavefront all of whose points qualify skips the ~55
+      instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer order; real orders are refused; spherical
@@ -318,8 +319,12 @@ class Compiler:
     #: (D5: 224, on: 0.592 -> 0.519 ms per 4096^2 sweep in round 2.  EGNO: 88, off: with it 0.409 -> 0.422 ms in round 3 --
     #: its quick point stage needs 20 spilled registers to keep three wavefronts per SIMD, or falls back to two.)
     HOIST_MIN_GAIN = 100
-    #: default of ``tan_shortcut`` (0 = off): profiles/r03_experiments.txt, the whole GPU parity suite is green with it
-    DEFAULT_TAN_SHORTCUT = 16
+    #: ``tan_shortcut`` of a default build: off -- eta_parallel is OCML's tan of OCML's atan, like the reference's is libm's
+    DEFAULT_TAN_SHORTCUT = 0
+    #: ``tan_shortcut`` of the profile-guided build (``regroup="auto"``) unless the caller says otherwise: that build
+    #: already trades the reference's bits for speed under a measured bound (profiles/r03_experiments.txt: the whole GPU
+    #: parity suite is green with 16)
+    TUNED_TAN_SHORTCUT = 16
 
     @staticmethod
     def quick_point_gain(info) -> int:
@@ -384,11 +389,10 @@ class Compiler:
         self.cse = cse
         self.max_cses = max_cses
         self.staged = staged
-        # (None: the environment variable INFLX_REGROUP, else off -- the switch the parity suite is run under for the
-        # regrouping experiments, profiles/r03_experiments.txt)
+        # (no environment switches in library code: what a default Compiler() computes depends on its arguments only;
+        # the experiment switches INFLX_REGROUP / INFLX_TAN_SHORTCUT live in workloads.artifact_for, test infrastructure)
         if regroup is None:
-            env = os.environ.get("INFLX_REGROUP", "0") or "0"
-            regroup = bool(int(env)) if env.isdigit() else tuple(env.split(","))
+            regroup = False
         self.sample = None
         if isinstance(regroup, str) and regroup == "auto":
             if sample is None:
@@ -410,7 +414,7 @@ class Compiler:
         self.share_reciprocals = bool(share_reciprocals)
         self.quick_sqrt = quick_sqrt  # None: wherever the quick point stage exists anyway (see the class docstring)
         if tan_shortcut is None:
-            tan_shortcut = float(os.environ.get("INFLX_TAN_SHORTCUT", "") or self.DEFAULT_TAN_SHORTCUT)
+            tan_shortcut = self.TUNED_TAN_SHORTCUT if self.regroup == "auto" else self.DEFAULT_TAN_SHORTCUT
         if tan_shortcut < 0 or tan_shortcut != int(tan_shortcut) or tan_shortcut >= 2**17:
             raise ValueError("tan_shortcut must be a whole number in [0, 2^17): the largest |v10/v00| for which tan(atan(t)) is taken as t")
         self.tan_shortcut = int(tan_shortcut)
@@ -512,6 +516,9 @@ class Compiler:
             # reference form's header, the sample and the instrument's criterion
             key = hashlib.sha256()
             key.update(header_for(False).encode())
+            # ... and the regrouped form that is measured against it (a change to the re-association logic of staging.py
+            # or to the options that shape the point stage must not find a stale decision)
+            key.update(header_for(frozenset(range(5))).encode())
             key.update(self.sample[0].tobytes() + np.asarray(self.sample[1], dtype=np.float64).tobytes())
             key.update(repr((_instrument.RTOL, _instrument.C_ERR, _instrument.COPIES)).encode())
             with open(_instrument.__file__, "rb") as fh:
@@ -575,12 +582,17 @@ class Compiler:
         opts = list(self.hipcc_opts)
         if self.gsl:
             opts.append("-DINFLX_USE_GSL=1")
-        # the tile kernels keep TILE_ROWS x n_row doubles of row-stage values in LDS: shrink the tile for
-        # models with very many row values so that it stays within ~64 KiB (two workgroups per CU)
-        n_row = max(1, (self.stage_info or {}).get("nr", 1))
+        # the tile kernels keep TILE_ROWS x kNRs doubles of row-stage values in LDS (kNRs = n_row rounded up to even, the
+        # stride the kernels use) beside their fixed LDS: the 12 KiB transpose buffers, the 34 polynomial coefficients of
+        # the epilogue and, for models with more than 8 parameter-only values, those values.  Shrink the tile for models
+        # with very many row values so that all of it stays within the 64 KiB of static LDS a kernel may declare
+        info = self.stage_info or {}
+        n_row = (max(1, info.get("nr", 1)) + 1) & ~1
+        n_uniform = max(1, info.get("nu", 1))
+        fixed_lds = 4 * 64 * 6 * 8 + 34 * 8 + (n_uniform * 8 if n_uniform > 8 else 0)
         if not any(o.startswith("-DINFLX_TILE_ROWS") for o in opts):
             rows = 32
-            while rows > 4 and rows * n_row * 8 > 64 * 1024:
+            while rows > 1 and rows * n_row * 8 + fixed_lds > 64 * 1024:
                 rows //= 2
             if rows != 32:
                 opts.append(f"-DINFLX_TILE_ROWS={rows}")

@@ -692,15 +692,19 @@ class Stager:
 def emit_stage_header(
     model, param_slots: dict, constants: dict, model_name: str, version: str, abi_version: str, staged: bool = True, cse=None, cse_vector=None, regroup: bool = False,
     hoist_reciprocals: bool = False,
-    share_point_reciprocals: bool = True,
-    quick_sqrt: bool = True,
+    share_point_reciprocals: bool = False,
+    quick_sqrt: bool | None = None,
 ):
     """Return (header text, info dict) for the model.
 
     ``cse``: ``None``, or a callable ``expr -> (replacements, reduced)`` reproducing the reference's
     per-function ``sympy.cse`` call (compiler.py:403-410); when given, the reference evaluates the
     cse'd form, so that form -- not the plain expression -- is what gets staged.  ``cse_vector``
-    is the list-valued variant the reference uses for the basis vectors (compiler.py:425-433)."""
+    is the list-valued variant the reference uses for the basis vectors (compiler.py:425-433).
+    The defaults of ``share_point_reciprocals`` (off) and ``quick_sqrt`` (``None``: follows ``hoist_reciprocals``) are
+    ``Compiler``'s, so that a direct caller generates the point stage a user gets."""
+    if quick_sqrt is None:
+        quick_sqrt = bool(hoist_reciprocals)
     x0, x1 = model.coordinates
     exprs = [
         sympy.sympify(model.potential),

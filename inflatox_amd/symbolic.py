@@ -404,3 +404,15 @@ class InflationModelBuilder:
             gradient_square=grad_sq,
             hesse_cmp=H_proj,
         )
+
+
+    def execute(self, guesses=None):
+        """The name this step has in the reference's README (README.md:72-73, ``calc.execute()``, from the releases in which
+        the builder was called ``SymbolicCalculation``); the same call as :meth:`build`."""
+        return self.build(guesses)
+
+
+#: the builder's name in the reference's README snippet (README.md:72: ``inflatox.SymbolicCalculation.new(fields, g, V)``);
+#: the reference renamed the class to ``InflationModelBuilder`` (symbolic.py:109) and left its README behind -- both names
+#: work here, so that the snippet BASELINE.json cites as the definition of the headline model runs with only the import changed
+SymbolicCalculation = InflationModelBuilder

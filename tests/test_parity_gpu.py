@@ -1153,13 +1153,16 @@ def test_broadcast_views_and_device_resident_result(gpu_lib):
 
 @pytest.mark.parametrize("name", ["doc", "egno"])
 def test_tan_shortcut_changes_eta_only_and_within_its_bound(name, gpu_lib):
-    """Compiler(tan_shortcut=16) (the default) takes tan(atan t) as t where t = |v10/v00| <= 16; tan_shortcut=0 evaluates
-    OCML's tan of OCML's atan.  The two builds agree bit for bit on consistency, eps_V, eps_H, delta and omega; eta =
+    """Compiler(tan_shortcut=16) (opt-in; what the profile-guided build uses) takes tan(atan t) as t where t = |v10/v00| <= 16;
+    the default, tan_shortcut=0, evaluates OCML's tan of OCML's atan.  The two builds agree bit for bit on consistency, eps_V, eps_H, delta and omega; eta =
     omega*tan(delta) - 3 differs by at most ~(t + 1/t + 2) * 2^-53 relative on omega*tan(delta), only where t <= 16."""
     import workloads
 
-    spec, art16 = workloads.artifact_for(name)
-    _, art0 = workloads.artifact_for(name, tan_shortcut=0)
+    from inflatox_amd import Compiler
+
+    assert Compiler.DEFAULT_TAN_SHORTCUT == 0 and Compiler(workloads.model_for(name), silent=True).tan_shortcut == 0
+    spec, art16 = workloads.artifact_for(name, tan_shortcut=16)
+    _, art0 = workloads.artifact_for(name)
     a, b = gpu_lib.InflatoxDevLib(art0.shared_object_path), gpu_lib.InflatoxDevLib(art16.shared_object_path)
     n0, n1 = 300, 520
     exact = a.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1)
@@ -1177,3 +1180,45 @@ def test_tan_shortcut_changes_eta_only_and_within_its_bound(name, gpu_lib):
     above = fin & (t > 16.5)
     assert np.array_equal(exact[..., 3][above], short[..., 3][above])  # beyond the bound both evaluate the tangent
     assert (diff[fin] > 0).any()  # and the shortcut is really in use
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc", "egno"])
+def test_default_build_is_ocml_tan_of_ocml_atan_through_the_sweep(name, gpu_lib, tmp_path):
+    """The default build (Compiler.DEFAULT_TAN_SHORTCUT = 0) reproduces `delta = (b / a).abs().atan()` and
+    `eta = omega * delta.tan() - 3.0` (src/anguelova.rs:128,132) with OCML as the libm BIT FOR BIT, asserted on what a sweep
+    stores: a probe kernel (tests/ocml_sweep_probe.hip: OCML's general atan / tan, contraction off) is fed the model
+    values and omega that the sweep itself produced at every grid point and must return the sweep's delta and eta."""
+    import subprocess
+
+    from inflatox_amd.compiler import hipcc_path
+
+    spec, art, lib = devlib(name, gpu_lib)
+    assert "-DINFLX_TAN_SHORTCUT_MAX" not in open(art.header_path).read()
+    n0, n1 = 257, 390
+    raw = lib.sweep_host(gpu_lib.OP_RAW, spec.args, spec.extent, n0, n1)
+    out = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1)
+    exe = tmp_path / "ocml_sweep_probe"
+    subprocess.run([hipcc_path(), "--offload-arch=gfx950", "-O3", "-fno-fast-math", "-ffp-contract=on", os.path.join(os.path.dirname(os.path.abspath(__file__)), "ocml_sweep_probe.hip"), "-o", str(exe)], check=True)
+    rec = np.ascontiguousarray(np.stack([raw[..., 1], raw[..., 2], out[..., 5]], axis=-1).reshape(-1, 3))
+    rec.tofile(tmp_path / "in.bin")
+    subprocess.run([str(exe), str(tmp_path / "in.bin"), str(tmp_path / "out.bin")], check=True, timeout=300)
+    want = np.fromfile(tmp_path / "out.bin", dtype=np.float64).reshape(n0, n1, 2)
+    assert np.array_equal(out[..., 4], want[..., 0], equal_nan=True)
+    assert np.array_equal(out[..., 3], want[..., 1], equal_nan=True)
+    assert np.isfinite(out[..., 3]).any() or name == "hyperbolic"  # (hyperbolic: eta is -3 or NaN everywhere, still compared)
+
+
+def test_config0_hyperbolic_256(gpu_lib):
+    """BASELINE configs[0] exactly as written: the README hyperbolic model, args [1, 1, 1], extent (-1, 1, -1, 1), 256 x 256
+    field grid, complete_analysis -- HIP through the front-end against the oracle (the restatement of the reference's
+    Rust/CPU path), the literal 1e-10 bar on all six arrays with no allowance, NaN / Inf patterns exact."""
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    om, _ = oracle_model("hyperbolic")
+    al = generalised_al(art)
+    got = np.stack(al.complete_analysis(np.array([1.0, 1.0, 1.0]), -1.0, 1.0, -1.0, 1.0, 256, 256, progress=False), axis=-1)
+    want = om.complete_analysis(np.array([1.0, 1.0, 1.0]), (-1.0, 1.0, -1.0, 1.0), 256, 256)
+    assert got.shape == want.shape == (256, 256, 6)
+    worst = compare(got, want, 1e-10, "configs[0] hyperbolic 256x256")
+    assert worst <= 1e-10
+    assert np.isnan(want[..., 0]).all()  # v10 = 0: the consistency quotient is NaN everywhere (SURVEY section 8c)
+    assert np.isfinite(want[..., 1]).all() and (want[..., 4] == 0).all()

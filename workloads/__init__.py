@@ -27,6 +27,24 @@ def model_for(name: str) -> InflationModel:
     return builder.build(spec.guesses)
 
 
+def _experiment_switches() -> dict:
+    """Experiment switches for runs of the whole parity suite / the probes under another build of the example models
+    (profiles/r03_experiments.txt): ``INFLX_REGROUP=1`` or a comma list of value names (``V,v00,g``), ``INFLX_TAN_SHORTCUT=T``.
+    They live here, in test / bench infrastructure: ``Compiler`` itself reads no environment variable."""
+    import os
+
+    out = {}
+    env = os.environ.get("INFLX_REGROUP", "")
+    if env:
+        if env == "auto":
+            raise ValueError('INFLX_REGROUP=auto: the measured choice needs a sample; use artifact_for(name, tuned=True)')
+        out["regroup"] = bool(int(env)) if env.isdigit() else tuple(env.split(","))
+    env = os.environ.get("INFLX_TAN_SHORTCUT", "")
+    if env:
+        out["tan_shortcut"] = float(env)
+    return out
+
+
 def artifact_for(name: str, tuned: bool = False, **compiler_overrides) -> tuple[example_models.ModelSpec, CompilationArtifact]:
     """``tuned``: the profile-guided build -- ``Compiler(regroup="auto", sample=(spec.args, spec.extent))``: products and
     sums of the model values that qualify on a sample of the workload's own parameter values and field range are
@@ -35,6 +53,8 @@ def artifact_for(name: str, tuned: bool = False, **compiler_overrides) -> tuple[
     kwargs = dict(spec.compiler_kwargs)
     if tuned:
         kwargs.update(regroup="auto", sample=(spec.args, spec.extent))
+    else:
+        kwargs.update(_experiment_switches())
     kwargs.update(compiler_overrides)
     art = Compiler(model_for(name), silent=True, **kwargs).compile()
     return spec, art
