@@ -397,6 +397,37 @@ def main():
     # L (the model's last parameter) in linspace(0.2, 2.0, 512), 64 rows per GPU: 8 GPUs sweep exactly that axis, fewer
     # GPUs its first 64 N rows (weak scaling: the work per GPU is fixed).  plan_shard hands every rank its block.
     rows_per_gpu = opt.rows_per_gpu if opt.rows_per_gpu else (1 if world == 1 else 64)
+    rows_requested = rows_per_gpu
+    if distributed:
+        assert dist.get_world_size() == opt.gpus == world, (dist.get_world_size(), opt.gpus, world)
+    # The result block stays resident: rows_per_gpu x 3.2 GB (206 GB at the default 64).  If a rank cannot allocate that
+    # (a GPU with less free HBM than a fresh MI355X offers, another tenant on the device), the block is halved until it fits --
+    # on EVERY rank, to the smallest size any rank got (weak scaling: the same work per GPU) -- in this process, and the line
+    # says which size ran (`config.parameter_rows_per_gpu`, `config.rows_per_gpu_requested`).  INFLX_BENCH_MAX_BLOCK_GB caps
+    # the block artificially (the two-rank rehearsal tests force the degrade path with it).
+    cap_gb = float(os.environ.get("INFLX_BENCH_MAX_BLOCK_GB", "0") or 0)
+    out = None
+    while True:
+        want_bytes = rows_per_gpu * N0 * N1 * 6 * 8
+        try:
+            if cap_gb and want_bytes > cap_gb * 1e9:
+                raise torch.OutOfMemoryError(f"INFLX_BENCH_MAX_BLOCK_GB={cap_gb}: refusing {want_bytes / 1e9:.1f} GB")
+            out = torch.empty((rows_per_gpu, N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
+            break
+        except (torch.OutOfMemoryError, RuntimeError) as exc:
+            if rows_per_gpu == 1:
+                raise
+            print(f"[bench rank {rank}] {rows_per_gpu} rows per GPU do not fit ({str(exc).splitlines()[0][:120]}): trying {rows_per_gpu // 2}", file=sys.stderr, flush=True)
+            rows_per_gpu //= 2
+            torch.cuda.empty_cache()
+    if distributed:
+        agreed = torch.tensor([rows_per_gpu], dtype=torch.int64, device=comm_device)
+        dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
+        if int(agreed.item()) != rows_per_gpu:
+            rows_per_gpu = int(agreed.item())
+            del out
+            torch.cuda.empty_cache()
+            out = torch.empty((rows_per_gpu, N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
     total_rows = rows_per_gpu * world
     all_rows = np.tile(np.array(spec.args, dtype=np.float64), (total_rows, 1))
     if total_rows > 1:
@@ -404,7 +435,8 @@ def main():
     plan = plan_shard(total_rows, N0, world, rank)
     assert plan.axis == "param" and plan.p_count == rows_per_gpu and plan.row_count == N0
     args = all_rows[plan.p_begin : plan.p_begin + plan.p_count]
-    out = torch.empty((rows_per_gpu, N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
+    device_name = torch.cuda.get_device_name(local_rank)
+    print(f"[bench rank {rank}/{world}] device {local_rank}: {device_name}, {torch.cuda.mem_get_info(local_rank)[0] / 1e9:.0f} GB free after allocating {out.numel() * 8 / 1e9:.1f} GB", file=sys.stderr, flush=True)
     # a stream of our own: torch's default stream has the NULL handle, which the C ABI reads as "the model's
     # own stream"; with an explicit one the HIP events below are recorded on the stream the kernels run on
     launch_stream = torch.cuda.Stream(device=f"cuda:{local_rank}")
@@ -477,6 +509,12 @@ def main():
         gbps = BYTES_PER_POINT * points / (k_ms * 1e-3) / 1e9
         per_rank.append({"rank": r, "kernel_ms": k_ms, "sweep_ms": s_ms, "step_ms_hip_events": e_ms, "achieved": gbps, "frac": gbps / HBM_PEAK_GBPS})
 
+    if distributed:
+        device_names = [None] * world
+        dist.all_gather_object(device_names, f"cuda:{local_rank} {device_name}")
+    else:
+        device_names = [f"cuda:{local_rank} {device_name}"]
+
     # outside the timed region: the statistics path of a sharded sweep -- every rank reduces its own block
     # on the device (summary-only sweep), three six-element all-reduces combine the ranks (RCCL when N > 1)
     stats_info = None
@@ -522,13 +560,15 @@ def main():
                 ),
                 "untimed_sweeps_before_warmup": settle_steps * rows_per_gpu,  # clock settling, see the comment at the warm-up loop
                 "parameter_rows_per_gpu": rows_per_gpu,
+                "rows_per_gpu_requested": rows_requested,  # larger than parameter_rows_per_gpu: the block was halved until every rank could allocate it
                 "parameter_rows_total": total_rows,
                 "baseline_config": "configs[1]" if total_rows == 1 else ("configs[4]" if (total_rows, N0) == (512, 8192) else f"configs[4] axis, first {total_rows} of 512 rows"),
                 "parallelism": (f"parameter-axis x{world} (plan_shard, no data-path collective)" if world > 1 else "single GPU") + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearse else ""),
             },
             "ranks": world,
             "comm_backend": (dist.get_backend() if distributed else None),
-            "rccl_ranks": (dist.get_world_size() if distributed and backend == "nccl" else 0),
+            "rccl_ranks": (dist.get_world_size() if distributed and dist.get_backend() == "nccl" else 0),
+            "devices": device_names,
             "roofline": {
                 "bound": "hbm",
                 "achieved": achieved,

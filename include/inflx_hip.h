@@ -87,8 +87,11 @@ int inflx_stage_info(const inflx_model* model, uint32_t* n_uniform, uint32_t* n_
  *   p           (n_p,)           model parameters
  *   start_stop  (2,2) row-major  [[x0_start,x0_stop],[x1_start,x1_stop]]  (src/lib.rs:117-139)
  *   out         (N0,N1,6) for complete_analysis, (N0,N1) for the single-quantity sweeps
- * `progress` != 0 prints the reference's start/finish lines to stderr; `threads` is accepted for
- * signature compatibility and ignored (the sweep runs on the GPU).
+ * `progress` != 0 prints the reference's start/finish lines to stderr and, while a call with a result of 1 GiB or more
+ * has been running for longer than 0.5 s, a progress line twice a second (time to completion, grid points/s,
+ * percentage: the figures of the reference's progress bar, src/anguelova.rs:42-50); `threads` is accepted for
+ * signature compatibility and ignored by these single-device entry points (the *_multi entry points below give it the
+ * reference's meaning, with GPUs as the workers).
  */
 int inflx_complete_analysis(inflx_model* model, const double* p, size_t n_p, double* out, const double* start_stop,
                             size_t N0, size_t N1, int progress, size_t threads); /* anguelova.rs:458-550 */
@@ -207,6 +210,42 @@ int inflx_sweep_device_stats(inflx_model* model, const double* p, size_t P, size
 
 /* wait for everything enqueued on the model's own stream */
 int inflx_synchronize(inflx_model* model);
+
+/*
+ * One call, several GPUs.  The reference's knob for "use the whole machine" is the `threads` argument of its sweeps:
+ * threads = None -> 0 -> a rayon pool over all cores (python/inflatox/consistency_conditions.py:297,
+ * src/anguelova.rs:185,236,524-540).  Here the workers are the node's GPUs: an `inflx_multi` is the model artefact opened
+ * on several devices (`devices` NULL or n_dev <= 0: every visible device; the same device may be listed more than once),
+ * and one call splits the outermost axis of the sweep into one contiguous balanced block per device --
+ *   the parameter axis when P >= devices, else the grid's row axis (inflx_shard_plan: plan = {axis (0 parameter rows,
+ *   1 grid rows), p_begin, p_count, row_begin, row_count}, the first n % world parts get one item more) --
+ * runs every device's pipeline (launch, device-to-host copy, page residency) on a host thread of its own and lets each
+ * device copy its slab straight into its place in the caller's array.  No exchange between devices is needed: every grid
+ * point and every parameter row is independent (the reference's threads do not communicate either).
+ *   inflx_sweep_host_multi:        as inflx_sweep_host for the whole grid; `out` is the whole (P, N0, N1, K) [AOS] or
+ *                                  (P, K, N0, N1) [SOA] array; `max_devices` = 0 uses every device of the handle, k > 0 the
+ *                                  first k; `progress` != 0 prints the start / finish lines and, for calls longer than
+ *                                  0.5 s, progress lines (time to completion, grid points/s, percentage: the figures of the
+ *                                  reference's progress bar, src/anguelova.rs:42-50) to stderr
+ *   inflx_complete_analysis_multi: the drop-in shape of libinflx_rs.complete_analysis (anguelova.rs:458-465) with
+ *                                  `threads` = 0: every device of the handle, k: at most k
+ *   inflx_sweep_stats_multi:       the summary of inflx_sweep_device_stats over the whole grid, every device reducing its
+ *                                  block inside its sweep kernels (no array is written), combined on the host
+ * Results are bit-identical to the single-device calls whatever the split: a grid point's value depends on its index
+ * and parameter row only.
+ */
+typedef struct inflx_multi inflx_multi;
+int inflx_shard_plan(size_t P, size_t N0, int world, int rank, size_t plan[5]);
+int inflx_open_multi(const char* artefact_path, const int* devices, int n_dev, inflx_multi** out);
+void inflx_close_multi(inflx_multi* multi);
+int inflx_multi_device_count(const inflx_multi* multi);
+inflx_model* inflx_multi_handle(const inflx_multi* multi, int index); /* the handle of device `index` (owned by `multi`) */
+int inflx_sweep_host_multi(inflx_multi* multi, int op, const double* p, size_t P, size_t n_p, double* out,
+                           const double* start_stop, size_t N0, size_t N1, int layout, int progress, size_t max_devices);
+int inflx_complete_analysis_multi(inflx_multi* multi, const double* p, size_t n_p, double* out, const double* start_stop,
+                                  size_t N0, size_t N1, int progress, size_t threads);
+int inflx_sweep_stats_multi(inflx_multi* multi, const double* p, size_t P, size_t n_p, const double* start_stop, size_t N0,
+                            size_t N1, size_t max_devices, inflx_summary* summary);
 
 #ifdef __cplusplus
 }

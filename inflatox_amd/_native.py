@@ -62,6 +62,14 @@ SIGNATURES = {
     "inflx_ops_on_values": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, C.c_int]),
     "inflx_validate_basis_at_random": (C.c_int, [C.c_void_p, C.c_uint64]),
     "inflx_validate_basis_on_domain": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), _SIZE, _DP, _SIZE, _DP, C.c_double]),
+    "inflx_shard_plan": (C.c_int, [_SIZE, _SIZE, C.c_int, C.c_int, C.POINTER(_SIZE)]),
+    "inflx_open_multi": (C.c_int, [C.c_char_p, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "inflx_close_multi": (None, [C.c_void_p]),
+    "inflx_multi_device_count": (C.c_int, [C.c_void_p]),
+    "inflx_multi_handle": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "inflx_sweep_host_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, C.c_int, _SIZE]),
+    "inflx_complete_analysis_multi": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
+    "inflx_sweep_stats_multi": (C.c_int, [C.c_void_p, _DP, _SIZE, _SIZE, _DP, _SIZE, _SIZE, _SIZE, C.c_void_p]),
 }
 
 
@@ -376,6 +384,94 @@ class InflatoxDevLib:
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))
+
+
+def shard_plan(P: int, N0: int, world: int, rank: int) -> dict:
+    """``inflx_shard_plan``: the block of the (parameter rows x grid rows) index space that part ``rank`` of ``world`` owns in a
+    multi-device sweep (no device needed)."""
+    plan = (_SIZE * 5)()
+    _check(load_library().inflx_shard_plan(P, N0, world, rank, plan))
+    return {"axis": ("param", "rows")[plan[0]], "p_begin": int(plan[1]), "p_count": int(plan[2]), "row_begin": int(plan[3]), "row_count": int(plan[4])}
+
+
+class InflatoxMultiLib:
+    """A model artefact opened on several HIP devices (``inflx_multi``): one call sweeps on all of them.
+
+    ``devices``: a sequence of device indices (a device may appear more than once) or ``"all"`` / ``None`` for every visible
+    device.  The counterpart of the reference's ``threads=0`` ("use the whole machine", anguelova.rs:524-540)."""
+
+    def __init__(self, artefact_path: str, devices="all"):
+        lib = load_library()
+        handle = C.c_void_p()
+        if devices is None or (isinstance(devices, str) and devices == "all"):
+            _check(lib.inflx_open_multi(os.fsencode(artefact_path), None, 0, C.byref(handle)))
+        else:
+            ids = [int(d) for d in devices]
+            if not ids:
+                raise ValueError("devices must name at least one device")
+            arr = (C.c_int * len(ids))(*ids)
+            _check(lib.inflx_open_multi(os.fsencode(artefact_path), arr, len(ids), C.byref(handle)))
+        self._h = handle
+        self._lib = lib
+        self.path = artefact_path
+        self.n_devices = int(lib.inflx_multi_device_count(handle))
+        self.devices = [int(lib.inflx_device_of(lib.inflx_multi_handle(handle, k))) for k in range(self.n_devices)]
+        first = lib.inflx_multi_handle(handle, 0)
+        self.n_parameters = int(lib.inflx_n_parameters(first))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.inflx_close_multi(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def complete_analysis(self, p, out, start_stop, progress=False, threads=0):
+        """``libinflx_rs.complete_analysis(lib, p, out, start_stop, progress, threads)`` (anguelova.rs:458) on the handle's
+        devices: ``threads`` = 0 uses all of them, k at most k."""
+        p = _f64(p, "p").reshape(-1)
+        ss = _f64(start_stop, "start_stop")
+        if ss.shape != (2, 2):
+            raise InflatoxShapeError(f"start_stop array should have 2 rows and as many columns as there are fields (got {ss.shape})")
+        if out.dtype != np.float64 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError("output array must be a writeable C-contiguous float64 array")
+        if out.ndim != 3 or out.shape[2] != 6:
+            raise InflatoxShapeError(f"Output array should be 3D. Last axis must have lenght 6 (got {out.shape})")
+        _check(self._lib.inflx_complete_analysis_multi(self._h, _ptr(p), p.size, _ptr(out), _ptr(ss), out.shape[0], out.shape[1], int(bool(progress)), int(threads)))
+
+    def sweep_host(self, op, p, start_stop, N0, N1, layout=LAYOUT_AOS, progress=False, max_devices=0, out=None) -> np.ndarray:
+        """P parameter rows x the whole grid -> host ndarray, every device sweeping and copying its own block."""
+        p = _f64(p, "p")
+        single = p.ndim == 1
+        p2 = p.reshape(1, -1) if single else p
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        P, k = p2.shape[0], OP_WIDTH[op]
+        if k == 1:
+            shape = (P, N0, N1)
+        elif layout == LAYOUT_AOS:
+            shape = (P, N0, N1, k)
+        else:
+            shape = (P, k, N0, N1)
+        if out is None:
+            from ._result_pool import result_array
+
+            out = result_array(shape)
+        elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous or not out.flags.writeable:
+            raise ValueError(f"out must be a writeable C-contiguous float64 array of shape {shape}")
+        _check(self._lib.inflx_sweep_host_multi(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, layout, int(bool(progress)), int(max_devices)))
+        return out[0] if single else out
+
+    def sweep_stats(self, p, start_stop, N0, N1, max_devices=0) -> dict:
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        out = Summary()
+        _check(self._lib.inflx_sweep_stats_multi(self._h, _ptr(p2), p2.shape[0], p2.shape[1], _ptr(ss), N0, N1, int(max_devices), C.byref(out)))
+        return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 
 
 def open_inflx_dylib(lib_path: str, check_basis: bool = True, device: int = 0) -> InflatoxDevLib:

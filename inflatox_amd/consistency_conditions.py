@@ -12,7 +12,7 @@ from __future__ import annotations
 import numpy as np
 
 from . import _native
-from ._native import InflatoxDevLib, open_inflx_dylib
+from ._native import InflatoxDevLib, InflatoxMultiLib, open_inflx_dylib
 from ._result_pool import result_array
 from .compiler import CompilationArtifact
 
@@ -27,8 +27,19 @@ def _start_stop(x0_start, x0_stop, x1_start, x1_stop) -> np.ndarray:
 class InflationCondition:
     """Base class: owns the opened model artefact (reference consistency_conditions.py:31-50)."""
 
-    def __init__(self, compiled_artifact: CompilationArtifact, validate_basis: bool = True, *, device: int = 0):
+    def __init__(self, compiled_artifact: CompilationArtifact, validate_basis: bool = True, *, device: int = 0, devices=None):
+        """``device`` (extension, keyword-only): the HIP device of this object.  ``devices`` (extension): a sequence of device
+        indices or ``"all"`` -- the grid sweeps (``complete_analysis`` and the single-quantity sweeps, the batch and summary
+        extensions) then run on ALL of them from one call: the outermost axis of the sweep is split into one block per
+        device and every device copies its block straight into the result array (``inflx_sweep_host_multi``).  This is the
+        meaning the reference gives its ``threads`` argument -- ``None`` -> 0 -> the whole machine
+        (consistency_conditions.py:297, anguelova.rs:524-540) -- with GPUs as the workers: ``threads=k`` limits a call to the
+        first k devices.  Default: one device, as before."""
         self.artifact = compiled_artifact
+        self.multi: InflatoxMultiLib | None = None
+        if devices is not None:
+            self.multi = InflatoxMultiLib(compiled_artifact.shared_object_path, devices)
+            device = self.multi.devices[0]
         self.dylib: InflatoxDevLib = open_inflx_dylib(compiled_artifact.shared_object_path, validate_basis, device=device)
 
     # -- scalar helpers (reference :52-65,103-117); evaluated on the device through the raw op ----
@@ -83,9 +94,9 @@ class GeneralisedAL(InflationCondition):
     """Generalised Anguelova-Lazaroiu consistency condition and the quantities derived from it
     (reference consistency_conditions.py:199-715)."""
 
-    def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0):
+    def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0, devices=None):
         # like the reference (consistency_conditions.py:222-224 -> :38), the constructor validates the basis
-        super().__init__(compiled_artifact, device=device)
+        super().__init__(compiled_artifact, device=device, devices=devices)
 
     # ---- the hot path ------------------------------------------------------------------------
     def complete_analysis(
@@ -130,7 +141,8 @@ class GeneralisedAL(InflationCondition):
         out = result_array((N_x0, N_x1, 6))
         start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
         threads = threads if threads is not None else 0
-        self.dylib.complete_analysis(args, out, start_stop, progress, threads)
+        # (with `devices=...` the call runs on all of them, `threads` limiting how many: the reference's "0 = whole machine")
+        (self.multi or self.dylib).complete_analysis(args, out, start_stop, progress, threads)
         return (out[:, :, 0], out[:, :, 1], out[:, :, 2], out[:, :, 3], out[:, :, 4], out[:, :, 5])
 
     def _constant_axis(self, N_x0: int, N_x1: int):
@@ -179,7 +191,7 @@ class GeneralisedAL(InflationCondition):
         or (P, 6, N_x0, N_x1) (``'soa'``) -- the outer parameter axis of the sweep in one call."""
         lay = {"aos": _native.LAYOUT_AOS, "soa": _native.LAYOUT_SOA}[layout]
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
-        return self.dylib.sweep_host(_native.OP_COMPLETE, np.atleast_2d(np.asarray(args, dtype=np.float64)), ss, N_x0, N_x1, layout=lay)
+        return (self.multi or self.dylib).sweep_host(_native.OP_COMPLETE, np.atleast_2d(np.asarray(args, dtype=np.float64)), ss, N_x0, N_x1, layout=lay)
 
     def complete_analysis_summary(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000) -> dict:
         """Extension: NaN-ignoring minimum, maximum and non-NaN count of the six quantities over the sweep,
@@ -187,13 +199,17 @@ class GeneralisedAL(InflationCondition):
         :meth:`complete_analysis` would give (the reference's tests do exactly that, tests/test_doc.py:58),
         without materialising or copying the arrays.  ``args`` may be (P, n_parameters)."""
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
-        return self.dylib.sweep_stats(args, ss, N_x0, N_x1)
+        return (self.multi or self.dylib).sweep_stats(args, ss, N_x0, N_x1)
 
     # ---- single-quantity sweeps (reference :310-475) ---------------------------------------------
     def _single(self, fn, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads):
         out = result_array((N_x0, N_x1))
         start_stop = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
         threads = threads if threads is not None else 0
+        if self.multi is not None:
+            op = {"consistency_only": _native.OP_CONSISTENCY, "epsilon_v_only": _native.OP_EPSILON_V, "consistency_rapidturn_only": _native.OP_RAPIDTURN}[fn.__name__]
+            self.multi.sweep_host(op, np.asarray(args, dtype=np.float64).reshape(1, -1), start_stop, N_x0, N_x1, progress=progress, max_devices=threads, out=out.reshape(1, N_x0, N_x1))
+            return out
         fn(args, out, start_stop, progress, threads)
         return out
 

@@ -13,12 +13,14 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cerrno>
 #include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
 #include <mutex>
 #include <future>
@@ -28,6 +30,9 @@
 #include <vector>
 
 #include <sys/mman.h>
+#if defined(__x86_64__)
+#include <emmintrin.h>
+#endif
 #include <unistd.h>
 
 #include "inflx_kernel_abi.h"
@@ -736,24 +741,6 @@ int check_basis(const double* basis, const double* x, size_t n, double accuracy,
   return INFLX_OK;
 }
 
-int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
-               int progress, const char* what) {
-  if (!out) return fail(INFLX_ERR_ARG, "output array is NULL");
-  if (!ss) return fail(INFLX_ERR_ARG, "start_stop array is NULL");
-  int rc = validate(m, op, p, 1, n_p);
-  if (rc) return rc;
-  const auto t0 = std::chrono::steady_clock::now();
-  if (progress) say("Calculating %s on HIP device %d (%s).", what, m->device, m->name.c_str());
-  rc = inflx_sweep_host(m, op, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS);
-  if (rc) return rc;
-  if (progress) {
-    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    say("Calculation finished. Took %.3f s (%.3g grid points/s including the copy to host memory).", sec,
-        (double)N0 * (double)N1 / std::max(sec, 1e-9));
-  }
-  return INFLX_OK;
-}
-
 }  // namespace
 
 extern "C" {
@@ -1198,9 +1185,201 @@ int inflx_validate_basis_on_domain(inflx_model* m, const uint32_t* num_points, s
 }  // extern "C"
 
 namespace {
-// host-result sweep for every operation; `out` holds kOpBytes[op] bytes per grid point
+
+// Where a slab lands in the caller's array.  The plain entry points hand over an array that holds exactly the slab
+// (dst_rows = row_count, dst_row0 = 0); a multi-device sweep hands every device the WHOLE array and the place of its
+// slab in it: element (p, k, row r of the slab) lives in block (p[, k]) of `dst_rows` grid rows at row dst_row0 + r.
+struct HostDest {
+  size_t dst_rows = 0;
+  size_t dst_row0 = 0;
+};
+
+// Bytes that have arrived in the caller's array, for the progress lines of long host-result calls (shared by the
+// devices of a multi-device sweep).
+struct Progress {
+  std::atomic<uint64_t> done{0};
+  uint64_t total = 0;
+};
+
+// One contiguous piece of the device-to-host transfer.
+struct Span {
+  size_t src, dst, bytes;  // byte offsets into the device buffer / the caller's array
+};
+
+// The spans that carry a device buffer laid out as the slab ([P][rc][N1][K] or [P][K][rc][N1], one byte per point for the
+// flag sweep) into the caller's array, merged where both sides are contiguous.
+std::vector<Span> transfer_spans(int op, size_t P, size_t N1, size_t row_count, int layout, const HostDest& d) {
+  const size_t K = kOpWidth[op];
+  const bool planes = layout == INFLX_SOA && K > 1;
+  const size_t blocks = planes ? P * K : P;                              // contiguous blocks of rows on both sides
+  const size_t row_bytes = planes ? N1 * sizeof(double) : N1 * kOpBytes[op];
+  std::vector<Span> spans;
+  for (size_t b = 0; b < blocks; ++b) {
+    const Span sp{b * row_count * row_bytes, (b * d.dst_rows + d.dst_row0) * row_bytes, row_count * row_bytes};
+    if (!spans.empty() && spans.back().src + spans.back().bytes == sp.src && spans.back().dst + spans.back().bytes == sp.dst)
+      spans.back().bytes += sp.bytes;
+    else
+      spans.push_back(sp);
+  }
+  return spans;
+}
+
+// ---- host-side broadcast of results that are constant along a grid axis ------------------------------------------------
+// A model none of whose values depends on x[1] (the README hyperbolic model) has a result in which every grid row is N1
+// copies of one record; one that ignores x[0] has a result whose grid rows are all the same image.  Such a result need not
+// cross PCIe: the one evaluated line does (hyperbolic 8192^2: 393 kB instead of 3.2 GB), and host threads write the
+// caller's array from it with streaming stores -- the same bytes in the same writable array (the reference's contract,
+// consistency_conditions.py:301-308), at the host's memory bandwidth instead of the link's.
+// INFLX_HOST_FILL=0 switches the path off (everything then goes through the device-to-host copy), INFLX_HOST_FILL_THREADS
+// sets the number of filling threads, INFLX_HOST_FILL_MIN_MB the smallest result that takes the path.
+bool host_fill_enabled() {
+  static const bool v = [] {
+    const char* e = getenv("INFLX_HOST_FILL");
+    return !(e && atoi(e) == 0);
+  }();
+  return v;
+}
+unsigned host_fill_threads() {
+  static const unsigned v = [] {
+    const char* e = getenv("INFLX_HOST_FILL_THREADS");
+    const long n = e ? atol(e) : 0;
+    return (unsigned)(n > 0 ? n : 32);  // hyperbolic 8192^2 on a GPU box's host share (16 CPUs of 256): 4 threads 52 ms, 8: 26, 16: 15.2, 32: 13.6, 64: 12.2
+  }();
+  return v;
+}
+size_t host_fill_min_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("INFLX_HOST_FILL_MIN_MB");
+    const long mb = e ? atol(e) : -1;
+    return (size_t)(mb >= 0 ? mb : 8) << 20;
+  }();
+  return v;
+}
+
+// dst[0 .. n*rec_bytes) = n copies of the record at `rec` (rec_bytes a multiple of 8, at most 64): streaming 16-byte stores
+// from a small periodic pattern, so that the freshly written array does not pass through the caches of the filling core
+void repeat_record(char* dst, const char* rec, size_t rec_bytes, size_t n) {
+  const size_t bytes = n * rec_bytes;
+#if defined(__x86_64__)
+  // pattern: 16 records (a multiple of 16 bytes whatever rec_bytes) and one more stretch, so that 64 bytes can be read at any phase
+  alignas(64) char pat[16 * 64 + 128];
+  const size_t period = 16 * rec_bytes;
+  for (size_t off = 0; off < period + 64; off += rec_bytes) memcpy(pat + off, rec, rec_bytes);
+  size_t done = 0;
+  const size_t head = std::min(bytes, (size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
+  if (head) {
+    memcpy(dst, pat, head);
+    done = head;
+  }
+  size_t phase = done % period;
+  for (; done + 64 <= bytes; done += 64) {
+    const char* src = pat + phase;
+    __m128d a, b, c, d;
+    memcpy(&a, src, 16), memcpy(&b, src + 16, 16), memcpy(&c, src + 32, 16), memcpy(&d, src + 48, 16);
+    _mm_stream_pd(reinterpret_cast<double*>(dst + done), a);
+    _mm_stream_pd(reinterpret_cast<double*>(dst + done + 16), b);
+    _mm_stream_pd(reinterpret_cast<double*>(dst + done + 32), c);
+    _mm_stream_pd(reinterpret_cast<double*>(dst + done + 48), d);
+    phase += 64;
+    if (phase >= period) phase -= period;
+  }
+  for (; done < bytes; ++done) {  // (< 64 bytes)
+    dst[done] = pat[phase];
+    if (++phase == period) phase = 0;
+  }
+#else
+  for (size_t k = 0; k < n; ++k) memcpy(dst + k * rec_bytes, rec, rec_bytes);
+#endif
+}
+
+// dst[0 .. bytes) = src[0 .. bytes) with streaming stores (the row image of a column-only model into one grid row)
+void stream_copy(char* dst, const char* src, size_t bytes) {
+#if defined(__x86_64__)
+  size_t done = std::min(bytes, (size_t)((16 - (reinterpret_cast<uintptr_t>(dst) & 15)) & 15));
+  if (done) memcpy(dst, src, done);
+  for (; done + 16 <= bytes; done += 16) {
+    __m128d a;
+    memcpy(&a, src + done, 16);
+    _mm_stream_pd(reinterpret_cast<double*>(dst + done), a);
+  }
+  if (done < bytes) memcpy(dst + done, src + done, bytes - done);
+#else
+  memcpy(dst, src, bytes);
+#endif
+}
+
+// Run fill(first, last) over [0, n) in contiguous blocks on up to host_fill_threads() threads (the calling thread takes one).
+template <typename F>
+void parallel_blocks(size_t n, size_t bytes_per_item, F fill) {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  size_t nthreads = std::min<size_t>(std::min(host_fill_threads(), hw), n);
+  nthreads = std::min<size_t>(nthreads, std::max<size_t>(1, n * bytes_per_item / (size_t(4) << 20)));  // at least 4 MiB per thread
+  std::vector<std::thread> pool;
+  auto block = [&](size_t t) {
+    const size_t a = n * t / nthreads, b = n * (t + 1) / nthreads;
+    if (b > a) fill(a, b);
+#if defined(__x86_64__)
+    _mm_sfence();
+#endif
+  };
+  std::vector<size_t> here{0};
+  for (size_t t = 1; t < nthreads; ++t) {
+    try {
+      pool.emplace_back(block, t);
+    } catch (...) {
+      here.push_back(t);
+    }
+  }
+  for (size_t t : here) block(t);
+  for (auto& th : pool) th.join();
+}
+
 int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
-                    size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy) {
+                    size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy, HostDest dest, Progress* progress);
+
+// The broadcast form of a host-result sweep (see above); `axis` = 1: nothing depends on x[1], 0: nothing depends on x[0].
+int sweep_host_broadcast(inflx_model* m, int op, int axis, const double* p, size_t P, size_t n_p, char* out, const double* ss, size_t N0,
+                         size_t N1, size_t row_begin, size_t row_count, int layout, const HostDest& dest, Progress* progress) {
+  const size_t K = kOpWidth[op];
+  const bool planes = layout == INFLX_SOA && K > 1;
+  const size_t rec = planes ? sizeof(double) : K * sizeof(double);  // bytes per grid point within one block of rows
+  const size_t blocks = planes ? P * K : P;
+  const size_t dst_row_bytes = N1 * rec;
+  for (size_t b = 0; b < blocks; ++b) advise_huge_pages(out + ((b * dest.dst_rows + dest.dst_row0) * N1) * rec, row_count * dst_row_bytes);
+  int rc;
+  if (axis == 1) {
+    // one column of the grid: (P, row_count, 1, K) resp. (P, K, row_count, 1)
+    std::vector<double> line(P * row_count * K);
+    if ((rc = sweep_host_impl(m, op, p, P, n_p, line.data(), ss, N0, 1, row_begin, row_count, layout, 0.0, HostDest(), nullptr))) return rc;
+    const char* src = reinterpret_cast<const char*>(line.data());
+    parallel_blocks(blocks * row_count, dst_row_bytes, [&](size_t first, size_t last) {
+      for (size_t q = first; q < last; ++q) {
+        const size_t b = q / row_count, r = q % row_count;
+        char* dst = out + ((b * dest.dst_rows + dest.dst_row0 + r) * N1) * rec;
+        repeat_record(dst, src + q * rec, rec, N1);
+        if (progress) progress->done += dst_row_bytes;
+      }
+    });
+    return INFLX_OK;
+  }
+  // one row of the grid: (P, 1, N1, K) resp. (P, K, 1, N1)
+  std::vector<double> image(P * N1 * K);
+  if ((rc = sweep_host_impl(m, op, p, P, n_p, image.data(), ss, N0, N1, row_begin, 1, layout, 0.0, HostDest(), nullptr))) return rc;
+  const char* src = reinterpret_cast<const char*>(image.data());
+  parallel_blocks(blocks * row_count, dst_row_bytes, [&](size_t first, size_t last) {
+    for (size_t q = first; q < last; ++q) {
+      const size_t b = q / row_count, r = q % row_count;
+      char* dst = out + ((b * dest.dst_rows + dest.dst_row0 + r) * N1) * rec;
+      stream_copy(dst, src + b * dst_row_bytes, dst_row_bytes);
+      if (progress) progress->done += dst_row_bytes;
+    }
+  });
+  return INFLX_OK;
+}
+
+// host-result sweep for every operation; the slab holds kOpBytes[op] bytes per grid point
+int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
+                    size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy, HostDest dest, Progress* progress) {
   INFLX_SERIALISE(m);
   char* const out = static_cast<char*>(out_v);
   int rc = validate(m, op, p, P, n_p);
@@ -1209,11 +1388,18 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
   if (row_count == 0 || N1 == 0) return INFLX_OK;
+  if (dest.dst_rows == 0) dest.dst_rows = row_count;
+  if (dest.dst_row0 + row_count > dest.dst_rows) return fail(INFLX_ERR_SHAPE, "slab rows [%zu,%zu) exceed the destination's %zu rows", dest.dst_row0, dest.dst_row0 + row_count, dest.dst_rows);
   HIP_TRY(hipSetDevice(m->device));
 
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
   const size_t total = P * row_count * row_bytes;
+  if (op != INFLX_OP_QDIF && host_fill_enabled() && total >= host_fill_min_bytes()) {
+    // a result that is constant along a grid axis is written by host threads from the one evaluated line
+    if ((m->info.out_mask & 2u) == 0 && N1 > 1) return sweep_host_broadcast(m, op, 1, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
+    if ((m->info.out_mask & 3u) == 2u && row_count > 1) return sweep_host_broadcast(m, op, 0, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
+  }
   bool whole = total <= whole_result_limit();
   if (whole && total > m->d_whole_cap) {
     if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
@@ -1233,42 +1419,82 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
   if (whole) {
-    // One launch for everything, one copy for everything: the device buffer has the layout of `out`.
-    // The destination pages are made resident by helper threads that run ahead of the copy: the first
-    // stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the resident
-    // frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
+    // One launch for everything, and as few copies as the destination allows (one when the caller's array is the slab):
+    // the device buffer has the layout of the slab.  The destination pages are made resident by helper threads that run
+    // ahead of the copy: the first stretch before the copy starts, the rest -- in stripes dealt round-robin, so that the
+    // resident frontier advances at the aggregate rate, several times the PCIe rate -- while it is under way.
     rc = launch_grid(m, op, d_params, P, static_cast<double*>(m->d_whole), ss, N0, N1, row_begin, row_count, layout, m->stream, 0, accuracy);
     if (rc) {  // kernels enqueued before the failure may still read the parameter slot
       (void)hipStreamSynchronize(m->side);
       (void)hipStreamSynchronize(m->stream);
       return rc;
     }
-    advise_huge_pages(out, total);
+    const std::vector<Span> spans = transfer_spans(op, P, N1, row_count, layout, dest);
+    // the destination as a sequence of stripes of at most 16 MiB, in transfer order
+    struct Stripe { char* at; size_t bytes; };
+    std::vector<Stripe> stripes;
+    const size_t stripe = size_t(16) << 20;
+    for (const Span& sp : spans) {
+      advise_huge_pages(out + sp.dst, sp.bytes);
+      for (size_t off = 0; off < sp.bytes; off += stripe) stripes.push_back({out + sp.dst + off, std::min(stripe, sp.bytes - off)});
+    }
     // helpers may only walk the destination while the copy is under way if their page touch is a real atomic
     // read-modify-write (touch_range); elsewhere everything is made resident before the copy starts
-    const size_t head = kTouchIsAtomic ? std::min<size_t>(total, size_t(64) << 20) : total;
-    prefault_range(out, head);
+    size_t head_stripes = 0;
+    for (size_t bytes = 0; head_stripes < stripes.size() && (!kTouchIsAtomic || bytes < (size_t(64) << 20)); ++head_stripes) {
+      prefault_range(stripes[head_stripes].at, stripes[head_stripes].bytes);
+      bytes += stripes[head_stripes].bytes;
+    }
     std::vector<std::thread> pool;
-    if (total > head) {
-      const size_t stripe = size_t(16) << 20;
-      const size_t nstripes = (total - head + stripe - 1) / stripe;
+    if (head_stripes < stripes.size()) {
+      const size_t rest = stripes.size() - head_stripes;
       const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), nstripes);
+      const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), rest);
       // helpers are an optimisation: the copy is correct without them (the runtime faults pages in itself,
       // slowly), so a thread that cannot be created is simply not there
       try {
         for (unsigned t = 0; t < nthreads; ++t)
-          pool.emplace_back([=] {
-            for (size_t k = t; k < nstripes; k += nthreads) {
-              const size_t off = head + k * stripe;
-              touch_range(out + off, std::min(stripe, total - off));
-            }
+          pool.emplace_back([&stripes, head_stripes, t, nthreads] {
+            for (size_t k = head_stripes + t; k < stripes.size(); k += nthreads) touch_range(stripes[k].at, stripes[k].bytes);
           });
       } catch (...) {
       }
     }
-    hipError_t e = hipMemcpyAsync(out, m->d_whole, total, hipMemcpyDeviceToHost, m->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    // Copies in slices of at most 256 MiB, all enqueued at once; with a progress sink an event behind every slice tells
+    // how far the transfer has come (the waits below cost nothing: the host has nothing else to do).
+    const size_t slice = size_t(256) << 20;
+    hipError_t e = hipSuccess;
+    std::vector<std::pair<hipEvent_t, size_t>> marks;
+    for (const Span& sp : spans) {
+      for (size_t off = 0; off < sp.bytes && e == hipSuccess; off += slice) {
+        const size_t n = std::min(slice, sp.bytes - off);
+        e = hipMemcpyAsync(out + sp.dst + off, static_cast<char*>(m->d_whole) + sp.src + off, n, hipMemcpyDeviceToHost, m->stream);
+        if (progress && e == hipSuccess) {
+          hipEvent_t ev = nullptr;
+          if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) == hipSuccess && hipEventRecord(ev, m->stream) == hipSuccess) {
+            marks.push_back({ev, n});
+          } else {
+            if (ev) (void)hipEventDestroy(ev);
+            marks.push_back({nullptr, n});
+          }
+        }
+      }
+    }
+    size_t unmarked = 0;
+    for (auto& mk : marks) {
+      if (mk.first) {
+        if (e == hipSuccess) e = hipEventSynchronize(mk.first);
+        (void)hipEventDestroy(mk.first);
+        if (e == hipSuccess) progress->done += mk.second;
+      } else {
+        unmarked += mk.second;
+      }
+    }
+    {
+      const hipError_t se = hipStreamSynchronize(m->stream);
+      if (e == hipSuccess) e = se;
+    }
+    if (progress && e == hipSuccess) progress->done += unmarked;
     for (auto& th : pool) th.join();
     // a buffer of many GiB is not kept between calls (the model would sit on that much HBM)
     if (m->d_whole_cap > (size_t(4) << 30)) {
@@ -1293,11 +1519,17 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   std::vector<Piece> pieces;
   for (size_t pr = 0; pr < P; ++pr)
     for (size_t r = 0; r < row_count; r += rows_per_chunk) pieces.push_back({pr, r, std::min(rows_per_chunk, row_count - r)});
+  const bool planes = layout == INFLX_SOA && K > 1;
+  // where rows [r, r + nrows) of parameter row pr (plane k) land in the caller's array
+  auto dst_of = [&](const Piece& pc, size_t k) {
+    return planes ? out + (((pc.pr * K + k) * dest.dst_rows) + dest.dst_row0 + pc.r) * N1 * sizeof(double)
+                  : out + ((pc.pr * dest.dst_rows) + dest.dst_row0 + pc.r) * row_bytes;
+  };
   auto touch = [&](const Piece& pc) {
-    if (layout == INFLX_AOS || K == 1) {
-      prefault_range(out + (pc.pr * row_count + pc.r) * row_bytes, pc.nrows * row_bytes);
+    if (!planes) {
+      prefault_range(dst_of(pc, 0), pc.nrows * row_bytes);
     } else {
-      for (size_t k = 0; k < K; ++k) prefault_range(out + ((pc.pr * K + k) * row_count + pc.r) * N1 * sizeof(double), pc.nrows * N1 * sizeof(double));
+      for (size_t k = 0; k < K; ++k) prefault_range(dst_of(pc, k), pc.nrows * N1 * sizeof(double));
     }
   };
   auto start_touch = [&](const Piece& pc) {
@@ -1317,11 +1549,19 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     (void)hipStreamSynchronize(m->stream);
     (void)hipStreamSynchronize(m->copy_stream);
   };
+  size_t counted = 0;  // pieces whose bytes the progress sink has been told about
   for (size_t c = 0; c < pieces.size(); ++c) {
     const Piece& pc = pieces[c];
     const int b = (int)(c & 1);
     // a chunk holds rows of a single parameter row: launch with P = 1 at that row's parameters
-    if (used[b] && hipStreamWaitEvent(m->stream, m->copy_done[b], 0) != hipSuccess) { drain(); return fail(INFLX_ERR_DEVICE, "hipStreamWaitEvent failed"); }
+    if (used[b]) {
+      // with a progress sink the host waits for the copy that frees this buffer (piece c - 2) instead of leaving the wait
+      // to the stream: it then knows how far the transfer has come, and stays two chunks ahead of it at most
+      hipError_t we = progress ? hipEventSynchronize(m->copy_done[b]) : hipStreamWaitEvent(m->stream, m->copy_done[b], 0);
+      if (we != hipSuccess) { drain(); return fail(INFLX_ERR_DEVICE, "waiting for a chunk copy failed: %s", hipGetErrorString(we)); }
+      if (progress)
+        for (; counted + 2 <= c; ++counted) progress->done += pieces[counted].nrows * row_bytes;
+    }
     rc = launch_grid(m, op, d_params + pc.pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + pc.r, pc.nrows, layout,
                      m->stream, 0, accuracy);
     if (rc) { drain(); return rc; }
@@ -1330,13 +1570,12 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     hipError_t e = hipEventRecord(m->chunk_done[b], m->stream);
     if (e == hipSuccess) e = hipStreamWaitEvent(m->copy_stream, m->chunk_done[b], 0);
     if (e == hipSuccess) {
-      if (layout == INFLX_AOS || K == 1) {
-        e = hipMemcpyAsync(out + (pc.pr * row_count + pc.r) * row_bytes, m->d_chunk[b], pc.nrows * row_bytes, hipMemcpyDeviceToHost, m->copy_stream);
+      if (!planes) {
+        e = hipMemcpyAsync(dst_of(pc, 0), m->d_chunk[b], pc.nrows * row_bytes, hipMemcpyDeviceToHost, m->copy_stream);
       } else {
         for (size_t k = 0; k < K && e == hipSuccess; ++k) {
-          char* dst = out + ((pc.pr * K + k) * row_count + pc.r) * N1 * sizeof(double);
           const double* src = static_cast<const double*>(m->d_chunk[b]) + k * pc.nrows * N1;
-          e = hipMemcpyAsync(dst, src, pc.nrows * N1 * sizeof(double), hipMemcpyDeviceToHost, m->copy_stream);
+          e = hipMemcpyAsync(dst_of(pc, k), src, pc.nrows * N1 * sizeof(double), hipMemcpyDeviceToHost, m->copy_stream);
         }
       }
     }
@@ -1347,7 +1586,171 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   if (ready.valid()) ready.wait();
   HIP_TRY(hipStreamSynchronize(m->copy_stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  if (progress)
+    for (; counted < pieces.size(); ++counted) progress->done += pieces[counted].nrows * row_bytes;
   return INFLX_OK;
+}
+
+// ---- progress lines of long host-result calls --------------------------------------------------------------------------
+// The reference draws an indicatif bar on stderr at 2 Hz while a sweep runs: time to completion, operations per second,
+// percentage (src/anguelova.rs:42-50, ticked once per grid point).  A sweep here is too short for a bar unless its result
+// is tens of gigabytes (PCIe at ~50 GB/s): a reporter thread prints the same three figures, from the bytes that have
+// arrived in the caller's array, first after 0.5 s and then twice a second -- calls shorter than that stay silent, and
+// only calls whose result is at least 1 GiB get a reporter at all.  (INFLX_PROGRESS_MIN_MB / INFLX_PROGRESS_INTERVAL_MS:
+// knobs for the tests.)
+size_t progress_min_bytes() {
+  static const size_t v = [] {
+    const char* e = getenv("INFLX_PROGRESS_MIN_MB");
+    const long mb = e ? atol(e) : -1;
+    return (size_t)(mb >= 0 ? mb : 1024) << 20;
+  }();
+  return v;
+}
+long progress_interval_ms() {
+  static const long v = [] {
+    const char* e = getenv("INFLX_PROGRESS_INTERVAL_MS");
+    const long ms = e ? atol(e) : 0;
+    return ms > 0 ? ms : 500L;
+  }();
+  return v;
+}
+
+class Reporter {
+ public:
+  Reporter(Progress* pr, double points, bool wanted) : pr_(pr), points_(points) {
+    if (!wanted || !pr || pr->total < progress_min_bytes()) return;
+    t0_ = std::chrono::steady_clock::now();
+    try {
+      th_ = std::thread([this] { run(); });
+    } catch (...) {  // no thread to be had: no progress lines
+    }
+  }
+  ~Reporter() {
+    if (!th_.joinable()) return;
+    {
+      std::lock_guard<std::mutex> g(mu_);
+      stop_ = true;
+    }
+    cv_.notify_all();
+    th_.join();
+  }
+  Reporter(const Reporter&) = delete;
+  Reporter& operator=(const Reporter&) = delete;
+
+ private:
+  void run() {
+    std::unique_lock<std::mutex> g(mu_);
+    const auto step = std::chrono::milliseconds(progress_interval_ms());
+    while (!cv_.wait_for(g, step, [this] { return stop_; })) {
+      const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0_).count();
+      const double frac = std::min(1.0, (double)pr_->done.load() / (double)std::max<uint64_t>(pr_->total, 1));
+      const double rate = frac * points_ / std::max(sec, 1e-9);
+      char eta[32];
+      if (frac > 0.0) snprintf(eta, sizeof eta, "%.1f s", sec * (1.0 - frac) / frac); else snprintf(eta, sizeof eta, "?");
+      say("Time to completion: %s | grid points/s: %.3g | %3.0f%%", eta, rate, 100.0 * frac);
+    }
+  }
+  Progress* pr_;
+  double points_;
+  std::chrono::steady_clock::time_point t0_;
+  std::thread th_;
+  std::mutex mu_;
+  std::condition_variable cv_;
+  bool stop_ = false;
+};
+
+int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+               int progress, const char* what) {
+  if (!out) return fail(INFLX_ERR_ARG, "output array is NULL");
+  if (!ss) return fail(INFLX_ERR_ARG, "start_stop array is NULL");
+  int rc = validate(m, op, p, 1, n_p);
+  if (rc) return rc;
+  const auto t0 = std::chrono::steady_clock::now();
+  if (progress) say("Calculating %s on HIP device %d (%s).", what, m->device, m->name.c_str());
+  Progress pr;
+  pr.total = (uint64_t)N0 * N1 * kOpBytes[op];
+  {
+    Reporter reporter(&pr, (double)N0 * (double)N1, progress != 0);
+    rc = sweep_host_impl(m, op, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, 0.0, HostDest(), progress ? &pr : nullptr);
+  }
+  if (rc) return rc;
+  if (progress) {
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    say("Calculation finished. Took %.3f s (%.3g grid points/s including the copy to host memory).", sec,
+        (double)N0 * (double)N1 / std::max(sec, 1e-9));
+  }
+  return INFLX_OK;
+}
+
+// The contiguous balanced block of `n_items` that part `rank` of `world` owns: the first n_items % world parts get one
+// item more (inflatox_amd/distributed.py block_bounds: one partition rule for the in-process and the one-process-per-GPU form).
+void block_bounds(size_t n_items, size_t world, size_t rank, size_t* begin, size_t* count) {
+  const size_t base = n_items / world, extra = n_items % world;
+  *begin = rank * base + std::min(rank, extra);
+  *count = base + (rank < extra ? 1 : 0);
+}
+
+struct ShardPlan {
+  int axis;  // 0 = the parameter axis is split, 1 = the grid's row axis
+  size_t p_begin, p_count, row_begin, row_count;
+};
+ShardPlan shard_plan(size_t P, size_t N0, size_t world, size_t rank) {
+  ShardPlan s;
+  if (P >= world) {
+    s.axis = 0;
+    block_bounds(P, world, rank, &s.p_begin, &s.p_count);
+    s.row_begin = 0;
+    s.row_count = N0;
+  } else {
+    s.axis = 1;
+    s.p_begin = 0;
+    s.p_count = P;
+    block_bounds(N0, world, rank, &s.row_begin, &s.row_count);
+  }
+  return s;
+}
+}  // namespace
+
+// One model artefact opened on several devices: the handles of a sweep that uses more than one GPU from one call.
+struct inflx_multi {
+  std::vector<inflx_model*> dev;
+  std::string path;
+};
+
+namespace {
+// Run `part(k)` for k in [0, n) -- one host thread per part, part 0 on the calling thread -- and report the first failure
+// (status and message) on the calling thread.
+template <typename F>
+int run_parts(size_t n, F part) {
+  std::vector<int> rcs(n, INFLX_OK);
+  std::vector<std::string> msgs(n);
+  auto body = [&](size_t k) {
+    rcs[k] = part(k);
+    if (rcs[k] != INFLX_OK) msgs[k] = g_last_error;  // thread-local: carried back by hand
+  };
+  std::vector<std::thread> pool;
+  std::vector<size_t> inline_parts{0};
+  for (size_t k = 1; k < n; ++k) {
+    try {
+      pool.emplace_back(body, k);
+    } catch (...) {  // no thread to be had: this part runs on the calling thread after its own
+      inline_parts.push_back(k);
+    }
+  }
+  for (size_t k : inline_parts)
+    if (k < n) body(k);
+  for (auto& th : pool) th.join();
+  for (size_t k = 0; k < n; ++k)
+    if (rcs[k] != INFLX_OK) {
+      g_last_error = msgs[k];
+      return rcs[k];
+    }
+  return INFLX_OK;
+}
+
+size_t devices_used(const inflx_multi* mm, size_t max_devices) {
+  const size_t n = mm->dev.size();
+  return max_devices ? std::min(n, max_devices) : n;
 }
 }  // namespace
 
@@ -1356,7 +1759,7 @@ extern "C" {
 int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
                      size_t N1, size_t row_begin, size_t row_count, int layout) {
   if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
-  return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, 0.0);
+  return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, 0.0, HostDest(), nullptr);
 }
 
 int inflx_flag_quantum_dif(inflx_model* m, const double* p, size_t n_p, uint8_t* out, const double* ss, size_t N0, size_t N1,
@@ -1364,7 +1767,7 @@ int inflx_flag_quantum_dif(inflx_model* m, const double* p, size_t n_p, uint8_t*
   if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   if (progress) say("Calculating zeros of the potential gradient on HIP device %d.", m->device);
-  return sweep_host_impl(m, INFLX_OP_QDIF, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, accuracy);
+  return sweep_host_impl(m, INFLX_OP_QDIF, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, accuracy, HostDest(), nullptr);
 }
 
 int inflx_complete_analysis(inflx_model* m, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
@@ -1413,6 +1816,147 @@ int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_
   HIP_TRY(hipModuleLaunchKernel(m->traj[op], (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
   HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  return INFLX_OK;
+}
+
+
+// ---- one call, several GPUs -------------------------------------------------------------------------------------------
+// The reference's knob for "use the whole machine" is `threads`: None -> 0 -> a rayon pool over all cores
+// (python/inflatox/consistency_conditions.py:297, src/anguelova.rs:524-540).  Here the machine's parallelism is its GPUs:
+// a multi-handle opens the artefact on several devices, and one call splits the outermost axis of the sweep into one
+// contiguous block per device (shard_plan: the parameter axis when there are at least as many parameter rows as devices,
+// the grid's rows otherwise -- the partition of inflatox_amd/distributed.py), runs every device's pipeline on a host thread
+// of its own, and lets each device copy its slab straight into its place in the caller's array.  No exchange between
+// devices: every grid point and every parameter row is independent.
+
+int inflx_shard_plan(size_t P, size_t N0, int world, int rank, size_t plan[5]) {
+  if (!plan) return fail(INFLX_ERR_ARG, "plan array is NULL");
+  if (world < 1 || rank < 0 || rank >= world) return fail(INFLX_ERR_ARG, "rank %d outside world of size %d", rank, world);
+  const ShardPlan s = shard_plan(P, N0, (size_t)world, (size_t)rank);
+  plan[0] = (size_t)s.axis;
+  plan[1] = s.p_begin;
+  plan[2] = s.p_count;
+  plan[3] = s.row_begin;
+  plan[4] = s.row_count;
+  return INFLX_OK;
+}
+
+int inflx_open_multi(const char* artefact_path, const int* devices, int n_dev, inflx_multi** out) {
+  if (!artefact_path || !out) return fail(INFLX_ERR_ARG, "artefact path / output handle is NULL");
+  *out = nullptr;
+  std::vector<int> ids;
+  if (!devices || n_dev <= 0) {  // every visible device
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0)
+      return fail(INFLX_ERR_DEVICE, "no HIP device available: the sweep has no CPU fallback");
+    for (int d = 0; d < count; ++d) ids.push_back(d);
+  } else {
+    ids.assign(devices, devices + n_dev);
+  }
+  inflx_multi* mm = new inflx_multi();
+  mm->path = artefact_path;
+  for (int d : ids) {
+    inflx_model* m = nullptr;
+    const int rc = inflx_open(artefact_path, d, &m);
+    if (rc != INFLX_OK) {
+      const std::string first = g_last_error;
+      inflx_close_multi(mm);
+      g_last_error = first;
+      return rc;
+    }
+    mm->dev.push_back(m);
+  }
+  *out = mm;
+  return INFLX_OK;
+}
+
+void inflx_close_multi(inflx_multi* mm) {
+  if (!mm) return;
+  for (inflx_model* m : mm->dev) inflx_close(m);
+  delete mm;
+}
+
+int inflx_multi_device_count(const inflx_multi* mm) { return mm ? (int)mm->dev.size() : 0; }
+
+inflx_model* inflx_multi_handle(const inflx_multi* mm, int index) {
+  if (!mm || index < 0 || (size_t)index >= mm->dev.size()) return nullptr;
+  return mm->dev[(size_t)index];
+}
+
+int inflx_sweep_host_multi(inflx_multi* mm, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
+                           size_t N1, int layout, int progress, size_t max_devices) {
+  if (!mm || mm->dev.empty()) return fail(INFLX_ERR_ARG, "multi-device handle is NULL or empty");
+  if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif on one device");
+  int rc = validate(mm->dev[0], op, p, P, n_p);
+  if (rc) return rc;
+  if (!out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
+  if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
+  if (N0 == 0 || N1 == 0) return INFLX_OK;
+  const size_t world = devices_used(mm, max_devices);
+  const auto t0 = std::chrono::steady_clock::now();
+  if (progress) say("Calculating on %zu HIP device(s) (%s): %zu parameter row(s) x %zu x %zu grid points.", world, mm->dev[0]->name.c_str(), P, N0, N1);
+  Progress pr;
+  pr.total = (uint64_t)P * N0 * N1 * kOpBytes[op];
+  {
+    Reporter reporter(&pr, (double)P * (double)N0 * (double)N1, progress != 0);
+    Progress* sink = progress ? &pr : nullptr;
+    rc = run_parts(world, [&](size_t k) -> int {
+      const ShardPlan s = shard_plan(P, N0, world, k);
+      if (s.p_count == 0 || s.row_count == 0) return INFLX_OK;
+      inflx_model* m = mm->dev[k];
+      if (s.axis == 0) {  // a block of parameter rows, every grid row: the slab is one contiguous piece of the array
+        char* dst = reinterpret_cast<char*>(out) + s.p_begin * N0 * N1 * kOpBytes[op];
+        return sweep_host_impl(m, op, p + s.p_begin * n_p, s.p_count, n_p, dst, ss, N0, N1, 0, N0, layout, 0.0, HostDest(), sink);
+      }
+      HostDest dest;  // every parameter row, a block of grid rows: rows [row_begin, row_begin + row_count) of every block
+      dest.dst_rows = N0;
+      dest.dst_row0 = s.row_begin;
+      return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, s.row_begin, s.row_count, layout, 0.0, dest, sink);
+    });
+  }
+  if (rc) return rc;
+  if (progress) {
+    const double sec = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    say("Calculation finished. Took %.3f s (%.3g grid points/s including the copy to host memory).", sec,
+        (double)P * (double)N0 * (double)N1 / std::max(sec, 1e-9));
+  }
+  return INFLX_OK;
+}
+
+int inflx_complete_analysis_multi(inflx_multi* mm, const double* p, size_t n_p, double* out, const double* ss, size_t N0, size_t N1,
+                                  int progress, size_t threads) {
+  // `threads` keeps the meaning it has in the reference (anguelova.rs:524: 0 = everything the machine has, k = at most k
+  // workers), with the handle's devices as the workers
+  return inflx_sweep_host_multi(mm, INFLX_OP_COMPLETE, p, 1, n_p, out, ss, N0, N1, INFLX_AOS, progress, threads);
+}
+
+int inflx_sweep_stats_multi(inflx_multi* mm, const double* p, size_t P, size_t n_p, const double* ss, size_t N0, size_t N1,
+                            size_t max_devices, inflx_summary* summary) {
+  if (!mm || mm->dev.empty()) return fail(INFLX_ERR_ARG, "multi-device handle is NULL or empty");
+  if (!summary) return fail(INFLX_ERR_ARG, "summary pointer is NULL");
+  int rc = validate(mm->dev[0], INFLX_OP_COMPLETE, p, P, n_p);
+  if (rc) return rc;
+  const size_t world = devices_used(mm, max_devices);
+  std::vector<inflx_summary> part(world);
+  for (auto& s : part)
+    for (int k = 0; k < 6; ++k) {
+      s.min[k] = HUGE_VAL;
+      s.max[k] = -HUGE_VAL;
+      s.count[k] = 0;
+    }
+  rc = run_parts(world, [&](size_t k) -> int {
+    const ShardPlan s = shard_plan(P, N0, world, k);
+    if (s.p_count == 0 || s.row_count == 0) return INFLX_OK;
+    return inflx_sweep_device_stats(mm->dev[k], p + s.p_begin * n_p, s.p_count, n_p, nullptr, 0, ss, N0, N1, s.row_begin, s.row_count, nullptr, &part[k]);
+  });
+  if (rc) return rc;
+  *summary = part[0];
+  for (size_t d = 1; d < world; ++d)
+    for (int k = 0; k < 6; ++k) {
+      summary->min[k] = std::fmin(summary->min[k], part[d].min[k]);
+      summary->max[k] = std::fmax(summary->max[k], part[d].max[k]);
+      summary->count[k] += part[d].count[k];
+    }
   return INFLX_OK;
 }
 

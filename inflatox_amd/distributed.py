@@ -74,29 +74,50 @@ class ShardedSweep:
         """Returns ``(plan, local_block)`` or, with ``gather``, ``(plan, full)`` where ``full`` has the
         shape (P, N0, N1, K) on every rank.  A world of one rank needs no exchange and returns its block as it is;
         ``force_collective`` sends it through the all-gather all the same (how the RCCL code path is exercised on a
-        one-GPU box: one rank, backend "nccl")."""
+        one-GPU box: one rank, backend "nccl").
+
+        Gather without copies: when every rank owns a block of the same size that is one contiguous piece of the result
+        (the parameter axis divides evenly -- BASELINE configs[4]: 512 rows over 8 GPUs --, or a single parameter row
+        whose grid rows divide evenly) and the compute step can write into a given tensor (``compute.allocates`` /
+        ``out=``: :class:`HipCompute`), the result is allocated once, the rank sweeps straight into its slice of it and the
+        all-gather runs in place on that buffer: no padded send copy, no ``world x`` receive buffer, no ``torch.cat``.
+        Unequal blocks and row-split batches take the padded path."""
         import torch
 
         args2d = np.atleast_2d(np.asarray(args2d, dtype=np.float64))
         P = args2d.shape[0]
         plan = plan_shard(P, N0, self.world, self.rank)
-        local = self.compute(args2d[plan.p_begin : plan.p_begin + plan.p_count], plan.row_begin, plan.row_count)
+        my_rows = args2d[plan.p_begin : plan.p_begin + plan.p_count]
         if not gather or (self.world == 1 and not force_collective):
-            return plan, local
+            return plan, self.compute(my_rows, plan.row_begin, plan.row_count)
         import torch.distributed as dist
 
+        n_items = P if plan.axis == "param" else N0
+        axis = 0 if plan.axis == "param" else 1
+        in_place = getattr(self.compute, "allocates", None) is not None and n_items % self.world == 0 and (plan.axis == "param" or P == 1)
+        if in_place:
+            full = self.compute.allocates((P, N0))  # (P, N0, N1, K), uninitialised, on the compute step's device
+            mine = full.narrow(axis, plan.p_begin if axis == 0 else plan.row_begin, n_items // self.world)
+            self.compute(my_rows, plan.row_begin, plan.row_count, out=mine)
+            # rank r's block is elements [r * count, (r + 1) * count) of the flat result: the in-place form of the all-gather
+            dist.all_gather_into_tensor(full.view(-1), mine.reshape(-1), group=self.group)
+            return plan, full
+        local = self.compute(my_rows, plan.row_begin, plan.row_count)
         local_t = local if isinstance(local, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(local))
         # equal-sized contributions: pad every block to the largest one along the sharded axis
-        n_items = P if plan.axis == "param" else N0
         biggest = block_bounds(n_items, self.world, 0)[1]
-        axis = 0 if plan.axis == "param" else 1
         pad_shape = list(local_t.shape)
         pad_shape[axis] = biggest
-        send = local_t.new_zeros(pad_shape)
-        send.narrow(axis, 0, local_t.shape[axis]).copy_(local_t)
+        if pad_shape == list(local_t.shape):
+            send = local_t.contiguous()
+        else:
+            send = local_t.new_zeros(pad_shape)
+            send.narrow(axis, 0, local_t.shape[axis]).copy_(local_t)
         recv = send.new_empty([self.world] + pad_shape)
         # flat views: the one calling convention both RCCL ("nccl") and gloo accept
-        dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=self.group)
+        dist.all_gather_into_tensor(recv.view(-1), send.view(-1), group=self.group)
+        if axis == 0 and n_items % self.world == 0:
+            return plan, recv.view([P] + pad_shape[1:])  # equal parameter blocks: the receive buffer IS the result
         pieces = []
         for r in range(self.world):
             _, count = block_bounds(n_items, self.world, r)
@@ -117,12 +138,25 @@ class HipCompute:
         # reads as "use the model's own stream", and that one is not ordered with torch's work
         self.stream = torch.cuda.Stream(device=f"cuda:{devlib.device}")
 
-    def __call__(self, p_rows, row_begin, row_count):
+    def allocates(self, outer):
+        """An uninitialised result tensor ``(*outer, N1, K)`` on this object's device (the gather buffer of
+        ``ShardedSweep.run``: the sweep writes every element of the slice it is given)."""
+        import torch
+
+        return torch.empty((*outer, self.N1, _native.OP_WIDTH[self.op]), dtype=torch.float64, device=torch.device(f"cuda:{self.lib.device}"))
+
+    def __call__(self, p_rows, row_begin, row_count, out=None):
+        """Sweep ``p_rows`` x grid rows [row_begin, row_begin + row_count) into a new tensor, or into ``out`` -- a
+        contiguous (len(p_rows), row_count, N1, K) tensor on this device, e.g. the rank's slice of a gather buffer."""
         import torch
 
         k = _native.OP_WIDTH[self.op]
         device = torch.device(f"cuda:{self.lib.device}")
-        out = torch.empty((len(p_rows), row_count, self.N1, k), dtype=torch.float64, device=device)
+        shape = (len(p_rows), row_count, self.N1, k)
+        if out is None:
+            out = torch.empty(shape, dtype=torch.float64, device=device)
+        elif tuple(out.shape) != shape or not out.is_contiguous() or out.dtype != torch.float64 or out.device != device:
+            raise ValueError(f"out must be a contiguous float64 tensor of shape {shape} on {device}")
         if out.numel():
             consumer = torch.cuda.current_stream(device)
             self.stream.wait_stream(consumer)  # `out` was allocated on the consumer's stream

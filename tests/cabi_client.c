@@ -59,6 +59,39 @@ int main(int argc, char** argv) {
     fprintf(stderr, "inflx_consistency_only failed (%d): %s\n", rc, inflx_last_error());
     return 7;
   }
+  /* one call, several GPUs: the artefact on two handles (device 0 twice -- a one-GPU box), the reference-shaped entry
+   * point with threads = 0 ("the whole machine", src/anguelova.rs:524-540); the slabs the two devices copy into `six2`
+   * must be the single-device result bit for bit, and the partition must be what inflx_shard_plan says */
+  {
+    const int devices[2] = {0, 0};
+    inflx_multi* multi = NULL;
+    rc = inflx_open_multi(argv[1], devices, 2, &multi);
+    if (rc != INFLX_OK || inflx_multi_device_count(multi) != 2) {
+      fprintf(stderr, "inflx_open_multi failed (%d): %s\n", rc, inflx_last_error());
+      return 10;
+    }
+    double* six2 = calloc(n0 * n1 * 6, sizeof(double));
+    rc = inflx_complete_analysis_multi(multi, p, n_p, six2, start_stop, n0, n1, 0, 0);
+    if (rc != INFLX_OK || memcmp(six, six2, n0 * n1 * 6 * sizeof(double)) != 0) {
+      fprintf(stderr, "inflx_complete_analysis_multi: status %d (%s) or a result that differs from the single-device one\n", rc, inflx_last_error());
+      return 11;
+    }
+    size_t plan[5];
+    if (inflx_shard_plan(1, n0, 2, 1, plan) != INFLX_OK || plan[0] != 1 || plan[3] != (n0 + 1) / 2 || plan[3] + plan[4] != n0) {
+      fprintf(stderr, "inflx_shard_plan: unexpected partition of %zu rows\n", n0);
+      return 12;
+    }
+    rc = inflx_complete_analysis_multi(multi, p, n_p + 1, six2, start_stop, n0, n1, 0, 0);
+    if (rc != INFLX_ERR_SHAPE) return 13;
+    inflx_summary whole, parts;
+    if (inflx_sweep_device_stats(model, p, 1, n_p, NULL, 0, start_stop, n0, n1, 0, n0, NULL, &whole) != INFLX_OK ||
+        inflx_sweep_stats_multi(multi, p, 1, n_p, start_stop, n0, n1, 0, &parts) != INFLX_OK || memcmp(&whole, &parts, sizeof whole) != 0) {
+      fprintf(stderr, "inflx_sweep_stats_multi differs from inflx_sweep_device_stats: %s\n", inflx_last_error());
+      return 14;
+    }
+    inflx_close_multi(multi);
+    free(six2);
+  }
   FILE* f = fopen(argv[8], "wb");
   if (!f) return 8;
   fwrite(six, sizeof(double), n0 * n1 * 6, f);

@@ -68,6 +68,32 @@ def _worker(rank, world, port, case, tmpdir):
         want = np.stack([om.grid_sweep(oracle.OP.COMPLETE, p, spec.extent, N0, N1) for p in args])
         assert tuple(full.shape) == want.shape, (full.shape, want.shape)
         assert np.array_equal(full.numpy(), want, equal_nan=True)
+
+        # the gather without copies: a compute step that can write into a given tensor (what HipCompute does on a GPU)
+        # sweeps straight into its slice of the one result buffer, and the all-gather runs in place on it
+        class WritesInPlace:
+            calls = []
+
+            def allocates(self, outer):
+                import torch
+
+                return torch.full((*outer, N1, 6), -1.0, dtype=torch.float64)
+
+            def __call__(self, p_rows, row_begin, row_count, out=None):
+                import torch
+
+                block = torch.from_numpy(compute(p_rows, row_begin, row_count))
+                self.calls.append(out is not None)
+                if out is None:
+                    return block
+                out.copy_(block)
+                return out
+
+        step = WritesInPlace()
+        plan_i, full_i = ShardedSweep(step, rank, world).run(args, N0, gather=True)
+        assert plan_i == plan and np.array_equal(full_i.numpy(), want, equal_nan=True)
+        n_items = P if plan.axis == "param" else N0
+        assert step.calls == [n_items % world == 0 and (plan.axis == "param" or P == 1)], step.calls  # in place exactly when blocks are equal and contiguous
         plan2, local = ShardedSweep(compute, rank, world).run(args, N0, gather=False)
         if plan2.axis == "param":
             assert np.array_equal(local, want[plan2.p_begin : plan2.p_begin + plan2.p_count], equal_nan=True)
@@ -83,7 +109,7 @@ def _worker(rank, world, port, case, tmpdir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("case", [("hyperbolic", 3, 12, 10), ("doc", 1, 13, 9)], ids=["param-axis", "row-axis"])
+@pytest.mark.parametrize("case", [("hyperbolic", 3, 12, 10), ("doc", 1, 13, 9), ("hyperbolic", 4, 6, 10), ("doc", 1, 14, 9)], ids=["param-axis", "row-axis", "param-axis-equal-blocks", "row-axis-equal-blocks"])
 def test_two_gloo_ranks_shard_and_gather(case, tmp_path):
     import torch.multiprocessing as mp
 

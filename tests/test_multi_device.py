@@ -1,0 +1,134 @@
+"""One call, several GPUs (include/inflx_hip.h: inflx_open_multi, inflx_sweep_host_multi, inflx_complete_analysis_multi,
+inflx_sweep_stats_multi): the partition on the CPU, and on an MI355X two / three handles on the one GPU (`devices=[0, 0]`)
+against the single-device call, bit for bit, on a parameter-axis split and on a row-axis split."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+def test_native_partition_equals_the_distributed_one_and_covers_the_index_space():
+    """inflx_shard_plan (the in-process, several-devices form) and distributed.plan_shard (one process per GPU) are the
+    same partition; blocks are contiguous, disjoint and cover (P, N0)."""
+    from inflatox_amd import _native
+    from inflatox_amd.distributed import plan_shard
+
+    for P, N0, world in [(1, 8192, 8), (512, 8192, 8), (32, 4096, 8), (5, 100, 4), (3, 7, 4), (1, 3, 8), (8, 1, 8), (9, 10, 2), (1, 1, 1), (2, 5, 3)]:
+        covered = np.zeros((P, N0), dtype=int)
+        for rank in range(world):
+            a, b = _native.shard_plan(P, N0, world, rank), plan_shard(P, N0, world, rank)
+            assert (a["axis"], a["p_begin"], a["p_count"], a["row_begin"], a["row_count"]) == (b.axis, b.p_begin, b.p_count, b.row_begin, b.row_count)
+            covered[a["p_begin"] : a["p_begin"] + a["p_count"], a["row_begin"] : a["row_begin"] + a["row_count"]] += 1
+        assert (covered == 1).all(), (P, N0, world)
+    with pytest.raises(ValueError):
+        _native.shard_plan(4, 4, 2, 2)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_two_handles_on_one_gpu_equal_the_single_device_result(name, gpu_lib):
+    """Parameter-axis split (P >= devices) and row-axis split (P < devices), AoS and SoA, ragged shapes, a device count
+    that does not divide the axis, every operation of the grid sweeps -- each against the single-device call."""
+    import workloads
+
+    spec, art = workloads.artifact_for(name)
+    one = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    two = gpu_lib.InflatoxMultiLib(art.shared_object_path, [0, 0])
+    three = gpu_lib.InflatoxMultiLib(art.shared_object_path, [0, 0, 0])
+    assert two.n_devices == 2 and two.devices == [0, 0] and three.n_devices == 3
+    rng = np.random.default_rng(7)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.8, 1.25, size=(5, len(spec.args)))
+    for multi in (two, three):
+        for layout in (gpu_lib.LAYOUT_AOS, gpu_lib.LAYOUT_SOA):
+            for P, n0, n1 in ((5, 37, 130), (2, 64, 96), (1, 45, 333), (1, 2, 64), (2, 7, 258)):
+                want = one.sweep_host(gpu_lib.OP_COMPLETE, rows[:P], spec.extent, n0, n1, layout=layout)
+                got = multi.sweep_host(gpu_lib.OP_COMPLETE, rows[:P], spec.extent, n0, n1, layout=layout)
+                assert got.shape == want.shape and np.array_equal(got, want, equal_nan=True), (multi.n_devices, layout, P, n0, n1)
+        for op in (gpu_lib.OP_CONSISTENCY, gpu_lib.OP_EPSILON_V, gpu_lib.OP_RAPIDTURN, gpu_lib.OP_RAW):
+            want = one.sweep_host(op, rows[:1], spec.extent, 33, 70, layout=gpu_lib.LAYOUT_SOA)
+            got = multi.sweep_host(op, rows[:1], spec.extent, 33, 70, layout=gpu_lib.LAYOUT_SOA)
+            assert np.array_equal(got, want, equal_nan=True), op
+        # max_devices = 1 is the single-device call through the multi-handle
+        assert np.array_equal(multi.sweep_host(gpu_lib.OP_COMPLETE, rows[:3], spec.extent, 20, 40, max_devices=1), one.sweep_host(gpu_lib.OP_COMPLETE, rows[:3], spec.extent, 20, 40), equal_nan=True)
+        # the summary: every device reduces its block inside its sweep, the host combines
+        a, b = one.sweep_stats(rows[:5], spec.extent, 90, 200), multi.sweep_stats(rows[:5], spec.extent, 90, 200)
+        b1 = multi.sweep_stats(rows[:1], spec.extent, 91, 200)  # row-axis split
+        a1 = one.sweep_stats(rows[:1], spec.extent, 91, 200)
+        for x, y in ((a, b), (a1, b1)):
+            assert np.array_equal(x["min"], y["min"]) and np.array_equal(x["max"], y["max"]) and np.array_equal(x["count"], y["count"])
+    # a wrong parameter count is refused with the shape error, and the handle stays usable
+    with pytest.raises(gpu_lib.InflatoxShapeError):
+        two.sweep_host(gpu_lib.OP_COMPLETE, np.ones((2, len(spec.args) + 1)), spec.extent, 8, 8)
+    assert np.isfinite(two.sweep_host(gpu_lib.OP_RAW, rows[:1], spec.extent, 8, 8)).any()
+
+
+@pytest.mark.gpu
+def test_front_end_with_devices(gpu_lib):
+    """GeneralisedAL(art, devices=[0, 0]): complete_analysis / the single-quantity sweeps / batch / summary equal the
+    single-device object's results; threads=1 limits the call to one device."""
+    import workloads
+    from inflatox_amd.consistency_conditions import GeneralisedAL, InflationCondition
+
+    spec, art = workloads.artifact_for("doc")
+
+    def make(**kw):
+        al = GeneralisedAL.__new__(GeneralisedAL)
+        InflationCondition.__init__(al, art, validate_basis=False, **kw)
+        return al
+
+    single, multi = make(), make(devices=[0, 0])
+    assert multi.multi is not None and multi.multi.n_devices == 2 and single.multi is None
+    for n0, n1 in ((101, 77), (1000, 1000)):
+        a = single.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False)
+        b = multi.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False)
+        c = multi.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False, threads=1)
+        assert all(np.array_equal(x, y, equal_nan=True) and np.array_equal(x, z, equal_nan=True) and y.flags.writeable for x, y, z in zip(a, b, c))
+    for meth in ("consistency", "epsilon_v", "consistency_rapidturn"):
+        assert np.array_equal(getattr(single, meth)(spec.args, *spec.extent, 65, 130, progress=False), getattr(multi, meth)(spec.args, *spec.extent, 65, 130, progress=False), equal_nan=True)
+    rows = np.tile(spec.args, (3, 1)) * np.array([[1.0], [1.5], [0.5]])
+    assert np.array_equal(single.complete_analysis_batch(rows, *spec.extent, 40, 50), multi.complete_analysis_batch(rows, *spec.extent, 40, 50), equal_nan=True)
+    s1, s2 = single.complete_analysis_summary(rows, *spec.extent, 64, 64), multi.complete_analysis_summary(rows, *spec.extent, 64, 64)
+    assert all(np.array_equal(s1[k], s2[k]) for k in ("min", "max", "count"))
+    all_devices = make(devices="all")
+    assert all_devices.multi.n_devices == gpu_lib.device_count()
+
+
+_CHUNKED = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import workloads
+from inflatox_amd import _native
+spec, art = workloads.artifact_for("doc")
+one = _native.InflatoxDevLib(art.shared_object_path)
+two = _native.InflatoxMultiLib(art.shared_object_path, [0, 0])
+rows = np.tile(spec.args, (3, 1)) * np.array([[1.0], [1.5], [0.5]])
+for layout in (0, 1):
+    for P in (3, 1):
+        want = one.sweep_host(_native.OP_COMPLETE, rows[:P], spec.extent, 300, 520, layout=layout)
+        got = two.sweep_host(_native.OP_COMPLETE, rows[:P], spec.extent, 300, 520, layout=layout, progress=True)
+        assert np.array_equal(got, want, equal_nan=True), (layout, P)
+print("chunked ok")
+"""
+
+
+@pytest.mark.gpu
+def test_chunk_pipeline_and_progress_lines_of_a_multi_device_sweep(gpu_lib):
+    """The same comparison through the chunk pipeline (results larger than the whole-result limit: forced with
+    INFLX_WHOLE_RESULT_MB=0 and 1 MiB chunks), with progress reporting switched on for any size and interval: the
+    reference's three figures (time to completion, operations per second, percentage; src/anguelova.rs:42-50) appear on
+    stderr, the results are unchanged."""
+    env = dict(os.environ, INFLX_WHOLE_RESULT_MB="0", INFLX_CHUNK_MB="1", INFLX_PROGRESS_MIN_MB="0", INFLX_PROGRESS_INTERVAL_MS="1")
+    proc = subprocess.run([sys.executable, "-c", _CHUNKED.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "chunked ok" in proc.stdout, proc.stdout + proc.stderr
+    lines = [ln for ln in proc.stderr.splitlines() if "Time to completion" in ln]
+    assert lines and all("grid points/s" in ln and "%" in ln for ln in lines), proc.stderr
+    assert "Calculating on 2 HIP device(s)" in proc.stderr and "Calculation finished" in proc.stderr
+    # ... and the whole-result path with progress marks (slices + events), default limits
+    env2 = dict(os.environ, INFLX_PROGRESS_MIN_MB="0", INFLX_PROGRESS_INTERVAL_MS="1")
+    proc2 = subprocess.run([sys.executable, "-c", _CHUNKED.format(root=ROOT)], env=env2, capture_output=True, text=True, timeout=600)
+    assert proc2.returncode == 0 and "chunked ok" in proc2.stdout, proc2.stdout + proc2.stderr
