@@ -157,7 +157,9 @@ class GSLInflatoxPrinter(CInflatoxPrinter):
             return f"gsl_sf_bessel_{integer_name}({n}, {x})"
         if real_name is None:
             raise KeyError("No non-integer impl found.")
-        return f"gsl_sf_bessel_{real_name}({self._print_Symbol(nu)}, {x})"
+        # (the reference prints the order with _print_Symbol too, i.e. a bare symbol; the orders nu +- 1 that differentiation
+        # produces are expressions and print as such here)
+        return f"gsl_sf_bessel_{real_name}({self._print_Symbol(nu) if (nu.is_Symbol or nu.is_number) else self._print(nu)}, {x})"
 
     _print_besselj = _print_bessely = _print_besseli = _print_besselk = _print_jn = _print_yn = _bessel
 
@@ -309,8 +311,8 @@ class Compiler:
       instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
-    (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer order; real orders are refused; spherical
-    ones of integer order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
+    (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order; spherical ones of integer
+    order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
     print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
     """
 

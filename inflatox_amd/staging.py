@@ -151,21 +151,20 @@ class HIPInflatoxPrinter(C99CodePrinter):
         return super()._print_Pow(expr)
 
     # -- special functions (reference: GSLInflatoxPrinter, compiler.py:123-212 -> gsl_sf_bessel_*) ------
-    # device counterparts live in csrc/inflx_sf.h; integer orders only (real orders are refused)
+    # device counterparts live in csrc/inflx_sf.h: integer orders by name / recurrence, real orders (a non-integer number,
+    # a model parameter, any expression) through inflx_sf_bessel_{J,Y,I,K}nu -- the reference's gsl_sf_bessel_*nu
     _CYLINDRICAL = {"besselj": "J", "bessely": "Y", "besseli": "I", "besselk": "K"}
     _SPHERICAL = {"jn": "j", "yn": "y"}
 
     def _bessel(self, expr, letter, named_orders, general):
         nu, arg = expr.args
-        if not (nu.is_number and nu.is_integer):
-            # real or symbolic order: gsl_sf_bessel_{J,Y,I,K}nu(nu, x) in the reference (compiler.py:199-212); there is no
-            # device counterpart in this package, and a silent substitute would be worse than a refusal
-            raise NotImplementedError(
-                f"{expr.func.__name__} of non-integer order {nu}: Bessel functions of real order have no device implementation "
-                "(integer orders, spherical functions of integer order and 0F1/1F1/2F1/2F0 do)"
-            )
-        n = int(nu)
         x = self._print(arg)
+        if not (nu.is_number and nu.is_integer):
+            if general != "n":
+                # the reference has no non-integer spherical functions either (compiler.py:196-198: "No non-integer impl found.")
+                raise KeyError(f"{expr.func.__name__} of non-integer order {nu}: no non-integer implementation (here as in the reference)")
+            return f"inflx_sf_bessel_{letter}nu({self._print(nu)}, {x})"
+        n = int(nu)
         if n in named_orders:
             return f"inflx_sf_bessel_{letter}{n}({x})"
         return f"inflx_sf_bessel_{letter}{general}({n}, {x})"

@@ -170,7 +170,7 @@ def test_hyperg_0F1_on_host_against_mpmath(sf, c):
     import mpmath as mp
 
     rng = np.random.default_rng(23)
-    x = np.concatenate([rng.uniform(-50, 50, 40), rng.uniform(-1, 1, 15), 10.0 ** rng.uniform(-8, -1, 8), -(10.0 ** rng.uniform(-8, -1, 8)), [0.0, 400.0, -400.0]])
+    x = np.concatenate([rng.uniform(-50, 50, 40), rng.uniform(-1, 1, 15), 10.0 ** rng.uniform(-8, -1, 8), -(10.0 ** rng.uniform(-8, -1, 8)), [0.0, 400.0, -400.0, -401.0, -2500.0, -1e5]])
     out = np.zeros_like(x)
     sf.sf_0F1(C.c_double(c), x.ctypes.data_as(DP), x.size, out.ctypes.data_as(DP))
     with mp.workdps(40):
@@ -190,7 +190,7 @@ def test_hyperg_0F1_on_host_against_mpmath(sf, c):
         assert np.isnan(bad).all()
 
 
-def test_0F1_model_on_host_twin_against_mpmath_and_real_orders_are_refused():
+def test_0F1_model_on_host_twin_against_mpmath():
     fields, metric, potential = example_models.bessel_0f1()
     model = InflationModelBuilder.new(fields, metric, potential, model_name="bessel_0f1", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
     comp = Compiler(model, silent=True, link_gsl=True)
@@ -208,18 +208,88 @@ def test_0F1_model_on_host_twin_against_mpmath_and_real_orders_are_refused():
     want = special.raw_values_mp(model, comp.symbol_dict, args, pts)
     scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
     assert np.isfinite(want).all() and (np.abs(got - want) / scale).max() < 1e-10
-    # what the reference's printer refuses is refused here as well -- loudly; Bessel functions of real order (which the
-    # reference hands to gsl_sf_bessel_*nu) have no device implementation and are refused too, never substituted
+    # what the reference's printer refuses is refused here as well -- loudly
     phi = model.coordinates[0]
-    nu = sympy.Symbol("nu")
-    for bad in (sympy.hyper([1, 2, 3], [4], phi / 9), sympy.jn(sympy.Rational(1, 2), phi), sympy.besselj(sympy.Rational(5, 2), phi), sympy.besselk(nu, phi + 1)):
+    for bad in (sympy.hyper([1, 2, 3], [4], phi / 9), sympy.jn(sympy.Rational(1, 2), phi)):
         m2 = InflationModelBuilder.new(fields, metric, bad + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
         with pytest.raises((NotImplementedError, KeyError, Exception)):  # KeyError / Exception: the reference printer's own refusals
             Compiler(m2, silent=True, link_gsl=True)._generate_hip_header()
-    for real_order in (sympy.besselj(sympy.Rational(5, 2), phi), sympy.besseli(nu, phi)):
-        m2 = InflationModelBuilder.new(fields, metric, real_order + 2, model_name="bad", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
-        with pytest.raises(NotImplementedError, match="real order"):
-            Compiler(m2, silent=True, link_gsl=True)._generate_hip_header()
+
+
+REAL_ORDERS = [0.0, 1e-12, 0.1, 0.25, 0.5, 0.75, 0.9999999, 1.0, 1.5, 2.3, 3.999, 7.5, 12.25, 20.0, 33.3, 75.5, 150.1]
+
+
+@pytest.mark.parametrize("kind", ["J", "Y", "I", "K"])
+def test_real_order_bessel_functions_on_host_against_mpmath(sf, kind):
+    """gsl_sf_bessel_{J,Y,I,K}nu's counterparts (csrc/inflx_sf.h: two integral representations of DLMF chapter 10 by the
+    trapezoidal rule, recurrences in their stable directions, Wronskians for the minimal solutions) against 40-digit values:
+    orders from 0 to 150 including integers and near-integers, arguments from 1e-100 to 1e5.  Bound: 1e-14 of the amplitude
+    sqrt(J^2 + Y^2) (of J itself where the order is above the argument and J is the minimal solution; of the function itself
+    for I and K), times x/10 for the phase error a large argument carries."""
+    import mpmath as mp
+
+    rng = np.random.default_rng(3)
+    xs = np.concatenate([10.0 ** rng.uniform(-12, 0, 12), rng.uniform(0, 4, 15), rng.uniform(4, 60, 25), rng.uniform(60, 400, 8), [1e-100, 1e3, 1e5]])
+    if kind in "IK":
+        xs = xs[xs < 300]
+    fn = {"J": mp.besselj, "Y": mp.bessely, "I": mp.besseli, "K": mp.besselk}[kind]
+    worst = 0.0
+    with mp.workdps(40):
+        for nu in REAL_ORDERS:
+            out = np.zeros_like(xs)
+            getattr(sf, f"sf_{kind}nu")(C.c_double(nu), xs.ctypes.data_as(DP), xs.size, out.ctypes.data_as(DP))
+            for xi, g in zip(xs, out):
+                want = fn(nu, mp.mpf(float(xi)))
+                if abs(want) > 1e300 or abs(want) < 1e-300:
+                    assert not np.isnan(g), (kind, nu, xi)
+                    continue
+                amp = abs(want)
+                if kind in "JY" and not (kind == "J" and nu >= xi):
+                    amp = mp.sqrt(mp.besselj(nu, xi) ** 2 + mp.bessely(nu, xi) ** 2)
+                err = float(abs(want - mp.mpf(float(g))) / amp) / max(1.0, xi / 10.0)
+                worst = max(worst, err)
+                assert err <= 1e-14, (kind, nu, xi, g, float(want), err)
+    print(f"{kind}nu: worst error {worst:.2e}")
+    # domains as in GSL: negative orders and (Y, K) non-positive arguments are domain errors -> NaN; J, I at x = 0
+    bad = np.zeros(3)
+    for name, x in (("Jnu", [-1.0, np.nan, 1.0]), ("Inu", [-1.0, np.nan, 1.0])):
+        getattr(sf, f"sf_{name}")(C.c_double(-0.5 if x[2] == 1.0 else 0.5), np.array(x).ctypes.data_as(DP), 3, bad.ctypes.data_as(DP))
+        assert np.isnan(bad).all()
+    for name in ("Ynu", "Knu"):
+        getattr(sf, f"sf_{name}")(C.c_double(0.5), np.array([0.0, -2.0, np.nan]).ctypes.data_as(DP), 3, bad.ctypes.data_as(DP))
+        assert np.isnan(bad).all()
+    z = np.zeros(1)
+    for name, nu, want in (("Jnu", 0.0, 1.0), ("Jnu", 0.5, 0.0), ("Inu", 0.0, 1.0), ("Inu", 2.5, 0.0)):
+        getattr(sf, f"sf_{name}")(C.c_double(nu), np.array([0.0]).ctypes.data_as(DP), 1, z.ctypes.data_as(DP))
+        assert z[0] == want
+
+
+def test_real_order_bessel_model_on_host_twin_against_mpmath():
+    """A model with Bessel functions of real order (a half-integer number and a model parameter; all four kinds): the
+    printer emits inflx_sf_bessel_*nu where the reference emits gsl_sf_bessel_*nu, orders shifted by differentiation
+    included, and the host twin's raw values agree with a 30-digit evaluation of the same sympy expressions."""
+    fields, metric, potential = example_models.bessel_real()
+    model = InflationModelBuilder.new(fields, metric, potential, model_name="bessel_real", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
+    comp = Compiler(model, silent=True, link_gsl=True)
+    hdr = comp._generate_hip_header()
+    for f in ("inflx_sf_bessel_Jnu(", "inflx_sf_bessel_Ynu(", "inflx_sf_bessel_Inu(", "inflx_sf_bessel_Knu("):
+        assert f in hdr, f
+    assert "inflx_sf_bessel_Knu(args[1]" in hdr or "inflx_sf_bessel_Knu(u_" in hdr  # the order is the model parameter nu (possibly staged)
+    assert comp.symbol_dict == {"phi": "x[0]", "theta": "x[1]", "m": "args[0]", "nu": "args[1]"}
+    # ... and the reference's printer strings for the same functions (compiler.py:199-212)
+    pr = GSLInflatoxPrinter(model.coordinates, model.coordinate_tangents)
+    nu = sympy.Symbol("nu")
+    assert pr.doprint(sympy.besselk(nu, model.coordinates[0])) == "gsl_sf_bessel_Knu(args[0], x[0])"
+    tw = HostTwin(hdr)
+    args = np.array([1.2, 2.6])
+    n0, n1, ext = 14, 6, (0.4, 9.0, 0.2, 2.9)
+    import oracle
+
+    pts = oracle.grid_points(ext, n0, n1)
+    got = tw.grid(4, args, ext, n0, n1).reshape(-1, 5)
+    want = special.raw_values_mp(model, comp.symbol_dict, args, pts)
+    scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
+    assert np.isfinite(want).all() and (np.abs(got - want) / scale).max() < 1e-10
 
 
 def _hyp(lib, name, params, x):

@@ -95,6 +95,68 @@ def test_integer_bessel_and_0F1_model_on_the_gpu(gpu_lib):
     assert np.isnan(bad[..., 0]).all()
 
 
+def test_real_order_bessel_model_on_the_gpu(gpu_lib):
+    """Bessel functions of real order (gsl_sf_bessel_{J,Y,I,K}nu in the reference, compiler.py:199-212) inside a model --
+    J_(5/2), I_(7/2), and K_nu, Y_nu with the order a model parameter, plus the orders differentiation shifts them to: the raw
+    values of a sweep against a 30-digit mpmath evaluation of the same sympy expressions, for two values of nu (one of
+    them an integer: the same code path)."""
+    from conftest import generalised_al
+    from workloads import example_models
+
+    model, comp, art = _build(example_models.bessel_real, "bessel_real", assertions=False, simplify=False)
+    al = generalised_al(art)
+    n0, n1, ext = 20, 8, (0.4, 9.0, 0.2, 2.9)
+    pts = oracle.grid_points(ext, n0, n1)
+    ss = np.array([[ext[0], ext[1]], [ext[2], ext[3]]])
+    for nu in (2.6, 3.0):
+        args = np.array([1.2, nu])
+        want = special.raw_values_mp(model, comp.symbol_dict, args, pts)
+        raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, ss, n0, n1).reshape(-1, 5)
+        scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
+        assert np.isfinite(want).all() and (np.abs(raw - want) / scale).max() < 1e-10, nu
+    # an order below GSL's domain (nu - 2 < 0 in the second derivatives): NaN, as GSL's domain error would have it
+    bad = al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 1.5]), ss, 4, 4)
+    assert np.isnan(bad[..., 1]).all() and np.isfinite(bad[..., 0]).all()
+
+
+@pytest.mark.parametrize("kind", ["J", "Y", "I", "K"])
+def test_real_order_bessel_device_functions_against_mpmath(kind, gpu_lib):
+    """Each real-order device function with its ORDER as a model parameter, probed through the raw-values kernel: orders
+    0 ... 75 (integers and near-integers included), arguments 1e-9 ... 400, against 40-digit values; bound as on the host
+    (1e-14 of the amplitude; of J itself above the turning point)."""
+    import mpmath as mp
+    import sympy
+
+    from inflatox_amd import Compiler, InflationModelBuilder
+    from inflatox_amd.consistency_conditions import InflationCondition
+
+    phi, theta, nu = sympy.symbols("phi theta nu")
+    fn_sym = {"J": sympy.besselj, "Y": sympy.bessely, "I": sympy.besseli, "K": sympy.besselk}[kind]
+    fn = {"J": mp.besselj, "Y": mp.bessely, "I": mp.besseli, "K": mp.besselk}[kind]
+    model = InflationModelBuilder.new([phi, theta], [[1, 0], [0, 1]], fn_sym(nu, phi), model_name=f"probe_{kind}nu", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
+    art = Compiler(model, silent=True, link_gsl=True).compile()
+    cond = InflationCondition(art, validate_basis=False)
+    rng = np.random.default_rng(4)
+    xs = np.concatenate([10.0 ** rng.uniform(-9, 0, 6), rng.uniform(0, 4, 8), rng.uniform(4, 60, 12), rng.uniform(60, 250 if kind in "IK" else 400, 4)])
+    pts = np.stack([xs, np.zeros_like(xs)], axis=1)
+    worst = 0.0
+    with mp.workdps(40):
+        for order in (0.0, 1e-12, 0.25, 0.5, 0.9999999, 1.0, 2.3, 7.5, 20.0, 33.3, 75.5):
+            got = cond.dylib.sweep_on_trajectory(gpu_lib.OP_RAW, np.array([order]), pts)[:, 0]
+            for xi, g in zip(xs, got):
+                want = fn(order, mp.mpf(float(xi)))
+                if abs(want) > 1e300 or abs(want) < 1e-300:
+                    assert not np.isnan(g), (kind, order, xi)
+                    continue
+                amp = abs(want)
+                if kind in "JY" and not (kind == "J" and order >= xi):
+                    amp = mp.sqrt(mp.besselj(order, xi) ** 2 + mp.bessely(order, xi) ** 2)
+                err = float(abs(want - mp.mpf(float(g))) / amp) / max(1.0, xi / 10.0)
+                worst = max(worst, err)
+                assert err <= 1e-14, (kind, order, xi, g, float(want), err)
+    print(f"{kind}nu: worst error on the device {worst:.2e}")
+
+
 def test_hypergeometric_model_on_the_gpu(gpu_lib):
     """1F1 and 2F1 (double-double series, noinline device functions) inside a model: raw values of a sweep
     against a 30-digit mpmath evaluation of the same sympy expressions; device-resident sweep included."""
@@ -146,7 +208,7 @@ def test_hypergeometric_device_functions_against_mpmath(family, gpu_lib):
     slot = [int(art.symbol_dictionary[n][5:-1]) for n in names]
     rng = np.random.default_rng(8)
     cases = {
-        "0F1": ([(0.5,), (1.5,), (3.7,), (25.5,), (-0.5,), (-2.3,)], np.concatenate([rng.uniform(-50, 50, 14), [1e-6, -1e-6, 400.0, -400.0]])),
+        "0F1": ([(0.5,), (1.5,), (3.7,), (25.5,), (-0.5,), (-2.3,)], np.concatenate([rng.uniform(-50, 50, 14), [1e-6, -1e-6, 400.0, -400.0, -401.0, -2500.0]])),
         "1F1": ([(0.5, 1.5), (-0.5, 1.0), (-3.0, 2.0), (4.2, -1.5), (12.5, 3.0), (-11.3, 4.0), (2.7, 2.7)], np.concatenate([rng.uniform(-30, 30, 10), [-300.0, 250.0, 1e-7, -80.0, 80.0]])),
         "2F1": ([(0.5, 0.5, 1.0), (1.0, 1.0, 2.0), (-0.5, 1.5, 2.5), (-3.0, 2.0, 1.5), (0.3, 0.7, -1.5), (2.0, 2.0, 4.5), (3.3, -1.2, 2.1), (2.3, 1.7, 1.0)],
                 np.concatenate([rng.uniform(-1, 1, 10), [-1.0, -0.7, 0.6, 0.93, 0.99, 0.999999]])),

@@ -219,11 +219,21 @@ def bessel_toy():
 
 def bessel_0f1():
     """Integer-order Bessel functions of both kinds and 0F1 in one potential: the functions the reference reaches
-    through gsl_sf_bessel_Jn / _Kn and gsl_sf_hyperg_0F1 (Bessel functions of real order have no device
-    implementation and are refused by the transpiler)."""
+    through gsl_sf_bessel_Jn / _Kn and gsl_sf_hyperg_0F1."""
     phi, theta = sp.symbols("phi theta")
     m, c = sp.symbols("m c")
     shape = 3 + sp.besselj(2, phi) + sp.besselk(1, phi + 1) + sp.hyper([], [c], -(phi**2) / 4)
+    potential = m**2 * shape * (1 + sp.cos(theta) / 10)
+    return [phi, theta], [[1, 0], [0, 1 + phi**2]], potential
+
+
+def bessel_real():
+    """Bessel functions of REAL order -- a half-integer number and a model parameter -- of all four kinds: what the reference
+    prints as gsl_sf_bessel_Jnu / _Ynu / _Inu / _Knu (compiler.py:199-212).  Differentiating shifts the orders by +-1 and
+    +-2, so with nu >= 2 every order the Hesse matrix needs stays in GSL's domain nu >= 0."""
+    phi, theta = sp.symbols("phi theta")
+    m, nu = sp.symbols("m nu")
+    shape = 4 + sp.besselj(sp.Rational(5, 2), phi) + sp.besselk(nu, phi + 1) + sp.bessely(nu, phi + 2) / 8 + sp.besseli(sp.Rational(7, 2), phi / 3) / 50
     potential = m**2 * shape * (1 + sp.cos(theta) / 10)
     return [phi, theta], [[1, 0], [0, 1 + phi**2]], potential
 
