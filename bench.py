@@ -44,7 +44,8 @@ FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full r
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
 # parameter-row sweeps (8192^2 each, ~0.45 ms) run untimed before the warm-up steps so that the clocks have settled: 64 = 29 ms
 SETTLE_ROW_SWEEPS = 64
-PROFILE_ROUNDS = ("03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json: newest first
+PROFILE_ROUNDS = ("04", "03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json, rNN_isa_mix.json: newest first
+SIMDS = 256 * 4
 
 
 def host_threads() -> int:
@@ -145,6 +146,30 @@ def self_launch(opt) -> int:
     return subprocess.run(cmd, env=env).returncode
 
 
+def issue_weighted(roof, key, code_id, pps):
+    """Add the issue-weighted VALU roofline of profiles/rNN_isa_mix.json (scripts/profile_isa_mix.sh) to a tile kernel's
+    roofline record: every VALU instruction class of the kernel's DYNAMIC mix (SQ_INSTS_VALU_* counters) priced with its
+    measured issue cost (quarter-rate v_rcp / v_rsq / v_sqrt_f64 = 3.1 fma slots, 32-bit ALU 0.7, profiles/r02_valu_rates.txt)
+    gives the SIMD cycles one grid point costs; `frac_issue_weighted` = points/s x that / (1024 SIMDs x shader clock), with the
+    clock the chip actually held in the profiled dispatch (GRBM_GUI_ACTIVE / 8 / duration) -- and, as
+    `frac_issue_weighted_at_2.4GHz`, with the nominal clock.  Only for the code object the counters were collected on."""
+    rec, src = recorded("isa_mix", key, code_id)
+    if not rec or "weighted_cycles_per_point" not in rec:
+        return roof
+    roof = dict(roof or {"bound": "valu"})
+    cyc, clk = rec["weighted_cycles_per_point"], rec.get("clock_GHz")
+    roof["weighted_cycles_per_point"] = cyc
+    roof["dynamic_mix_per_point"] = rec.get("dynamic_mix_per_point")
+    roof["frac_issue_weighted_at_2.4GHz"] = pps * cyc / (SIMDS * 2.4e9)
+    if clk:
+        roof["shader_clock_GHz_under_this_kernel"] = clk
+        roof["peak_points_per_s_issue_weighted"] = SIMDS * clk * 1e9 / cyc
+        roof["frac_issue_weighted"] = pps * cyc / (SIMDS * clk * 1e9)
+        roof["frac_issue_weighted_in_the_profiled_dispatch"] = rec.get("frac_issue_weighted")
+    roof["isa_mix_source"] = src
+    return roof
+
+
 def secondary_workloads(_native, workloads, torch, np, device, stream, only=None, builds=("default", "tuned")):
     """BASELINE configs[2] and [3] on this GPU, kernel time by HIP events on the launch stream (no part of `value`).
     These are FP64-VALU-bound: the roofline that prices them is the VALU issue rate, from
@@ -177,7 +202,7 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
             rec = {
                 "workload": text,
                 "kernel": "inflx_sweep_tile_complete",
-                "build": "default: the reference's arithmetic (Compiler(...) as the reference's tests call it)",
+                "build": "default: the reference's arithmetic (Compiler(...) as the reference's tests call it; tan_shortcut off: eta is OCML's tan of OCML's atan)",
                 "ms": ms,
                 "timing": f"HIP events around {repeats} back-to-back launches, best of 3 such batches",
                 "points_per_s": pps,
@@ -196,6 +221,7 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                     "valu_insts_per_point": ipp,
                     "source": src,
                 }
+            rec["roofline"] = issue_weighted(rec["roofline"], name, cid, pps)
             # the profile-guided build of the same workload (Compiler(regroup="auto", sample=(args, extent)): the model values
             # that a host measurement on the workload's own parameter values and field range clears are re-associated;
             # same parity criteria, tests/test_tuned_gpu.py) -- reported beside the default build, never instead of it
@@ -206,13 +232,14 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                 lib_t = _native.InflatoxDevLib(art_t.shared_object_path, device=device)
                 ms_t = min(lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
                 rec["profile_guided"] = {
-                    "build": 'Compiler(regroup="auto", sample=(args, extent))',
+                    "build": 'Compiler(regroup="auto", sample=(args, extent)): measured re-association, tan(atan t) -> t for t <= 16',
                     "regrouped_values": art_t.stage_info.get("regrouped"),
                     "ms": ms_t,
                     "points_per_s": P * n * n / (ms_t * 1e-3),
                     "hbm_frac": BYTES_PER_POINT * P * n * n / (ms_t * 1e-3) / 1e9 / HBM_PEAK_GBPS,
                     "code_object": code_object_id(art_t),
                 }
+                rec["profile_guided"]["roofline"] = issue_weighted(None, name + ":tuned", code_object_id(art_t), rec["profile_guided"]["points_per_s"])
                 del lib_t
             except LookupError:
                 pass
@@ -313,8 +340,8 @@ def end_to_end(workloads, np, model: str, n: int, device: int):
         "ms": warm * 1e3,
         "points_per_s": n * n / warm,
         "GBps": BYTES_PER_POINT * n * n / warm / 1e9,
-        "default_cold": rec(cold, "first call: fresh host pages, PCIe copy of the whole (N0, N1, 6) array"),
-        "default_warm": rec(warm, "best of 3 repeated calls: result memory recycled by the result pool, PCIe copy of the whole array"),
+        "default_cold": rec(cold, "first call: fresh host pages; the model ignores x1, so one evaluated column crosses PCIe and host threads write the caller's writable (N0, N1, 6) array from it (csrc/inflx_hip.cpp sweep_host_broadcast)"),
+        "default_warm": rec(warm, "best of 3 repeated calls: result memory recycled by the result pool, same host-side broadcast fill"),
         "broadcast_views": rec(lean, "opt-in broadcast_views=True, best of 5: one evaluated line copied, six read-only stride-0 views (only where the model ignores one field)"),
         "device_resident": rec(dev, "complete_analysis_device, best of 5 incl. synchronisation: six torch views of a device tensor (DLPack / __cuda_array_interface__), nothing crosses PCIe"),
     }

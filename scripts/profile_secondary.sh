@@ -6,7 +6,7 @@
 # prints for it (HIP-event ms, points/s, code-object tag) next to the profile's average kernel duration.
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-RND=${1:-03}
+RND=${1:-04}
 O=$R/gpurun_out/prof_secondary
 rm -rf $O && mkdir -p $O && cd /tmp && export TMPDIR=/tmp
 for W in d5 egno doc d5:tuned egno:tuned doc:tuned; do

@@ -5,7 +5,7 @@
 # scripts/valu_report.py merges the databases into profiles/rNN_valu.json (stamped with the code objects' hashes).
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-RND=${1:-03}
+RND=${1:-04}
 O=$R/gpurun_out/prof_tile
 rm -rf $O && mkdir -p $O && cd /tmp && export TMPDIR=/tmp
 export INFLX_PROBE_STAMP=$O/code_objects.json
