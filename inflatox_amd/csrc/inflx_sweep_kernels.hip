@@ -69,12 +69,7 @@
 
 static_assert(INFLX_DIM == 2, "the sweep kernels need a two-field model (Hesse2D, hesse_bindings.rs:203)");
 
-// threads per workgroup (and columns per tile of the tile kernels).  256 everywhere; the store-stream kernels rely on
-// kThreads == 1 (mod 3), and the host launches every kernel with INFLX_KERNEL_INFO.tile_cols threads
-#ifndef INFLX_THREADS
-#define INFLX_THREADS 256
-#endif
-constexpr int kThreads = INFLX_THREADS;
+constexpr int kThreads = 256;
 constexpr int kWave = 64;
 constexpr int kTileRows = INFLX_TILE_ROWS;
 constexpr int kRowsPerBlock = INFLX_ROWS_PER_BLOCK;
