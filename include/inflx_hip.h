@@ -246,6 +246,23 @@ int inflx_complete_analysis_multi(inflx_multi* multi, const double* p, size_t n_
                                   size_t N0, size_t N1, int progress, size_t threads);
 int inflx_sweep_stats_multi(inflx_multi* multi, const double* p, size_t P, size_t n_p, const double* start_stop, size_t N0,
                             size_t N1, size_t max_devices, inflx_summary* summary);
+/*
+ * Device-resident results on several GPUs (no counterpart in the reference; the exchange step SURVEY section 8e allows
+ * "when the result must be device-resident on every GPU").
+ *   inflx_sweep_device_multi:    device k sweeps its block (inflx_shard_plan with world = the handle's device count, rank = k)
+ *                                into d_out[k], device memory ON device k laid out as the block; asynchronous, enqueued on
+ *                                streams[k] (NULL array / entry: the handle's own stream).  No data crosses a link.
+ *   inflx_sweep_allgather_multi: every d_full[k] (device memory on device k, the whole (P, N0, N1, K) AOS array) holds the
+ *                                whole result on return.  Each device sweeps its block in place into its slice of its own
+ *                                buffer and pushes the slice to every peer with hipMemcpyPeerAsync on a stream per peer:
+ *                                xGMI is point to point, the n - 1 pushes of a device use n - 1 links at once (a direct
+ *                                all-to-all broadcast, slab / link-rate instead of a ring's (n - 1) steps).  Synchronous.
+ */
+int inflx_sweep_device_multi(inflx_multi* multi, int op, const double* p, size_t P, size_t n_p, void* const* d_out,
+                             const size_t* d_out_bytes, const double* start_stop, size_t N0, size_t N1, int layout,
+                             void* const* streams);
+int inflx_sweep_allgather_multi(inflx_multi* multi, int op, const double* p, size_t P, size_t n_p, void* const* d_full,
+                                size_t d_full_bytes, const double* start_stop, size_t N0, size_t N1);
 
 #ifdef __cplusplus
 }

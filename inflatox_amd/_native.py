@@ -70,6 +70,8 @@ SIGNATURES = {
     "inflx_sweep_host_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, C.c_int, _SIZE]),
     "inflx_complete_analysis_multi": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _DP, _SIZE, _SIZE, C.c_int, _SIZE]),
     "inflx_sweep_stats_multi": (C.c_int, [C.c_void_p, _DP, _SIZE, _SIZE, _DP, _SIZE, _SIZE, _SIZE, C.c_void_p]),
+    "inflx_sweep_device_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.POINTER(C.c_void_p), C.POINTER(_SIZE), _DP, _SIZE, _SIZE, C.c_int, C.POINTER(C.c_void_p)]),
+    "inflx_sweep_allgather_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.POINTER(C.c_void_p), _SIZE, _DP, _SIZE, _SIZE]),
 }
 
 
@@ -464,6 +466,27 @@ class InflatoxMultiLib:
             raise ValueError(f"out must be a writeable C-contiguous float64 array of shape {shape}")
         _check(self._lib.inflx_sweep_host_multi(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, layout, int(bool(progress)), int(max_devices)))
         return out[0] if single else out
+
+    def sweep_device(self, op, p, d_out_ptrs, d_out_bytes, start_stop, N0, N1, layout=LAYOUT_AOS, streams=None):
+        """Device k sweeps its block (``shard_plan(P, N0, n_devices, k)``) into ``d_out_ptrs[k]`` (device memory on device k, laid
+        out as the block); asynchronous on ``streams[k]`` (``None``: the handle's own stream)."""
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        n = self.n_devices
+        ptrs = (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in d_out_ptrs])
+        sizes = (_SIZE * n)(*[int(v) for v in d_out_bytes])
+        st = None if streams is None else (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in streams])
+        _check(self._lib.inflx_sweep_device_multi(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, sizes, _ptr(ss), N0, N1, layout, st))
+
+    def sweep_allgather(self, op, p, d_full_ptrs, d_full_bytes, start_stop, N0, N1):
+        """Every ``d_full_ptrs[k]`` (device memory on device k, the whole (P, N0, N1, K) array) holds the whole result on return:
+        each device sweeps its block in place and pushes it to every peer over its own xGMI link (``hipMemcpyPeerAsync``)."""
+        p2 = _f64(p, "p")
+        p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        ptrs = (C.c_void_p * self.n_devices)(*[C.c_void_p(int(v)) for v in d_full_ptrs])
+        _check(self._lib.inflx_sweep_allgather_multi(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, int(d_full_bytes), _ptr(ss), N0, N1))
 
     def sweep_stats(self, p, start_stop, N0, N1, max_devices=0) -> dict:
         p2 = _f64(p, "p")

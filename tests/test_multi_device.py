@@ -132,3 +132,42 @@ def test_chunk_pipeline_and_progress_lines_of_a_multi_device_sweep(gpu_lib):
     env2 = dict(os.environ, INFLX_PROGRESS_MIN_MB="0", INFLX_PROGRESS_INTERVAL_MS="1")
     proc2 = subprocess.run([sys.executable, "-c", _CHUNKED.format(root=ROOT)], env=env2, capture_output=True, text=True, timeout=600)
     assert proc2.returncode == 0 and "chunked ok" in proc2.stdout, proc2.stdout + proc2.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_device_resident_multi_sweep_and_peer_all_gather(name, gpu_lib):
+    """inflx_sweep_device_multi (every device keeps its block) and inflx_sweep_allgather_multi (every device ends up with the
+    whole result: in-place sweep into the device's slice, then one hipMemcpyPeerAsync per peer) with two and three handles
+    on the one GPU, parameter-axis and row-axis split, equal and unequal blocks -- against the single-device host result."""
+    import torch
+
+    import workloads
+
+    spec, art = workloads.artifact_for(name)
+    one = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    rng = np.random.default_rng(11)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.8, 1.25, size=(5, len(spec.args)))
+    for devices in ([0, 0], [0, 0, 0]):
+        multi = gpu_lib.InflatoxMultiLib(art.shared_object_path, devices)
+        n = multi.n_devices
+        for P, n0, n1 in ((4, 36, 130), (5, 37, 70), (1, 64, 96), (1, 45, 333), (2, 7, 258)):
+            want = one.sweep_host(gpu_lib.OP_COMPLETE, rows[:P], spec.extent, n0, n1).reshape(P, n0, n1, 6)
+            # every device the whole result
+            full = [torch.full((P, n0, n1, 6), -5.0, dtype=torch.float64, device="cuda:0") for _ in range(n)]
+            torch.cuda.synchronize()
+            multi.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:P], [t.data_ptr() for t in full], full[0].numel() * 8, spec.extent, n0, n1)
+            for k, t in enumerate(full):
+                assert np.array_equal(t.cpu().numpy(), want, equal_nan=True), (devices, P, n0, n1, k)
+            # every device its own block
+            plans = [gpu_lib.shard_plan(P, n0, n, k) for k in range(n)]
+            blocks = [torch.full((max(pl["p_count"], 1), max(pl["row_count"], 1), n1, 6), -5.0, dtype=torch.float64, device="cuda:0") for pl in plans]
+            torch.cuda.synchronize()
+            multi.sweep_device(gpu_lib.OP_COMPLETE, rows[:P], [b.data_ptr() for b in blocks], [b.numel() * 8 for b in blocks], spec.extent, n0, n1)
+            torch.cuda.synchronize()  # (a device-wide wait: the handles' own streams included)
+            for pl, b in zip(plans, blocks):
+                if pl["p_count"] and pl["row_count"]:
+                    ref = want[pl["p_begin"] : pl["p_begin"] + pl["p_count"], pl["row_begin"] : pl["row_begin"] + pl["row_count"]]
+                    assert np.array_equal(b.cpu().numpy(), ref, equal_nan=True), (devices, P, n0, n1, pl)
+        with pytest.raises(gpu_lib.InflatoxShapeError):
+            multi.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:2], [t.data_ptr() for t in full], 8, spec.extent, 8, 8)
