@@ -494,33 +494,56 @@ def test_config3_d5_4096_x_32_parameter_rows_in_one_call(gpu_lib):
     torch.cuda.empty_cache()
 
 
-def test_config5_per_gpu_share_hyperbolic_8192_x_64(gpu_lib):
-    """The per-GPU share of BASELINE configs[4] (8192 x 8192 x 512 parameter rows over 8 GPUs): 64 parameter rows
-    (L in linspace(0.2, 2.0, 512)[:64]) in ONE call, 206 GB device-resident, 16 table batches.
-    Every column equals column 0; column 0 of every parameter row equals the oracle's 8192 x 1 sweep."""
+def test_config4_all_eight_per_gpu_shares_hyperbolic_8192_x_512(gpu_lib):
+    """BASELINE configs[4] at its full size -- the hyperbolic 8192 x 8192 grid x the 512-row parameter axis L = linspace(0.2,
+    2.0, 512) -- as the eight per-GPU shares `plan_shard(512, 8192, 8, rank)` hands out, swept ONE AFTER THE OTHER on this one
+    GPU (an 8-GPU node sweeps them side by side; nothing is exchanged, so the per-share results are the same): each share is
+    ONE call of 64 parameter rows into 206 GB of HBM (16 table batches), 1.65 TB of results in all.  For every one of the
+    512 parameter rows: every column equals column 0 (the model ignores x1), and column 0 equals the oracle's 8192 x 1 sweep
+    at that row's parameters to the literal 1e-10 bar; the per-share device summaries, combined like all_reduce_summary
+    combines the ranks', equal numpy over the oracle's values."""
     import torch
 
+    from inflatox_amd.distributed import numpy_summary, plan_shard
+
     spec, art, lib = devlib("hyperbolic", gpu_lib)
-    n, P = 8192, 64
-    rows = np.tile(spec.args, (P, 1))
-    rows[:, 2] = np.linspace(0.2, 2.0, 512)[:P]
-    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n, n) == {"path": "row_stream", "batch_rows": 4, "batches": 16, "replicas": 32}
+    n, total, world = 8192, 512, 8
+    axis = np.linspace(0.2, 2.0, total)
+    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, total // world, n, n) == {"path": "row_stream", "batch_rows": 4, "batches": 16, "replicas": 32}
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
-    need = P * n * n * 48
+    need = (total // world) * n * n * 48
     if free < need + (8 << 30):
         pytest.skip(f"needs {need / 2**30:.0f} GiB of free HBM, {free / 2**30:.0f} GiB available")
-    out = torch.empty((P, n, n, 6), dtype=torch.float64, device="cuda:0")
-    lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    out = torch.empty((total // world, n, n, 6), dtype=torch.float64, device="cuda:0")
     om, _ = oracle_model("hyperbolic")
-    for k in range(P):
-        col0 = out[k, :, :1, :]
-        same = (out[k] == col0) | (torch.isnan(out[k]) & torch.isnan(col0))
-        assert bool(same.all()), k
-        del same
-        want = om.grid_sweep(OP.COMPLETE, rows[k], spec.extent, n, 1)[:, 0, :]
-        compare(col0[:, 0, :].cpu().numpy(), want, 1e-10, f"hyperbolic 8192^2 x 64, parameter row {k}")
+    combined = None
+    oracle_cols = []
+    for rank in range(world):
+        plan = plan_shard(total, n, world, rank)
+        assert (plan.axis, plan.p_count, plan.row_begin, plan.row_count) == ("param", 64, 0, n) and plan.p_begin == 64 * rank
+        rows = np.tile(spec.args, (plan.p_count, 1))
+        rows[:, 2] = axis[plan.p_begin : plan.p_begin + plan.p_count]
+        out.fill_(-7.0)
+        lib.sweep_device(gpu_lib.OP_COMPLETE, rows, out.data_ptr(), out.numel() * 8, spec.extent, n, n, stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        for k in range(plan.p_count):
+            col0 = out[k, :, :1, :]
+            same = (out[k] == col0) | (torch.isnan(out[k]) & torch.isnan(col0))
+            assert bool(same.all()), (rank, k)
+            del same
+            want = om.grid_sweep(OP.COMPLETE, rows[k], spec.extent, n, 1)[:, 0, :]
+            compare(col0[:, 0, :].cpu().numpy(), want, 1e-10, f"configs[4] rank {rank}, parameter row {plan.p_begin + k}")
+            oracle_cols.append(want)
+        part = lib.sweep_stats(rows, spec.extent, n, n)  # the share's summary, reduced inside the sweep kernels
+        if combined is None:
+            combined = part
+        else:  # MIN / MAX / SUM, what all_reduce_summary does across ranks
+            combined = {"min": np.minimum(combined["min"], part["min"]), "max": np.maximum(combined["max"], part["max"]), "count": combined["count"] + part["count"]}
+    whole = numpy_summary(np.stack(oracle_cols))  # every grid row's values count N1 times
+    assert np.array_equal(combined["count"], whole["count"] * np.uint64(n))
+    fin = np.isfinite(whole["min"])
+    assert np.allclose(combined["min"][fin], whole["min"][fin], rtol=1e-10, atol=0) and np.allclose(combined["max"][fin], whole["max"][fin], rtol=1e-10, atol=0)
     del out
     torch.cuda.empty_cache()
 
