@@ -575,7 +575,11 @@ class Compiler:
 
     def _hipcc_compile(self, header_text: str):
         kernel_src = os.path.join(_CSRC, "inflx_sweep_kernels.hip")
-        deps = [kernel_src] + [os.path.join(_CSRC, f) for f in ("inflx_ops.h", "inflx_device_math.h", "inflx_kernel_abi.h", "inflx_sf.h", "inflx_sf_tables.h")]
+        deps = [kernel_src] + [os.path.join(_CSRC, f) for f in ("inflx_ops.h", "inflx_device_math.h", "inflx_kernel_abi.h")]
+        # the special-function header is part of a code object only when the model calls into it (every function in it is an
+        # inline device function: unreferenced ones leave no trace in the binary)
+        if "inflx_sf_" in header_text:
+            deps += [os.path.join(_CSRC, f) for f in ("inflx_sf.h", "inflx_sf_tables.h")]
         h = hashlib.sha256()
         h.update(header_text.encode())
         for d in deps:
