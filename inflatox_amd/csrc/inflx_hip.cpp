@@ -1441,9 +1441,20 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     // helpers may only walk the destination while the copy is under way if their page touch is a real atomic
     // read-modify-write (touch_range); elsewhere everything is made resident before the copy starts
     size_t head_stripes = 0;
-    for (size_t bytes = 0; head_stripes < stripes.size() && (!kTouchIsAtomic || bytes < (size_t(64) << 20)); ++head_stripes) {
-      prefault_range(stripes[head_stripes].at, stripes[head_stripes].bytes);
-      bytes += stripes[head_stripes].bytes;
+    {
+      char* run_at = nullptr;  // stripes that follow each other in memory are made resident by ONE call (its threads share the run)
+      size_t run_bytes = 0;
+      for (size_t bytes = 0; head_stripes < stripes.size() && (!kTouchIsAtomic || bytes < (size_t(64) << 20)); ++head_stripes) {
+        const Stripe& st = stripes[head_stripes];
+        if (run_bytes && run_at + run_bytes != st.at) {
+          prefault_range(run_at, run_bytes);
+          run_bytes = 0;
+        }
+        if (!run_bytes) run_at = st.at;
+        run_bytes += st.bytes;
+        bytes += st.bytes;
+      }
+      if (run_bytes) prefault_range(run_at, run_bytes);
     }
     std::vector<std::thread> pool;
     if (head_stripes < stripes.size()) {
