@@ -104,3 +104,20 @@ def test_two_rank_rehearsal_degrades_when_the_block_does_not_fit():
     assert abs(line["value"] - 2 * 16 * 2048 * 2048 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-9
     assert len(line["devices"]) == 2 and all("cuda:0" in d for d in line["devices"])
     assert line["summary_sweep"]["non_nan"][1] == 2 * 16 * 2048 * 2048
+
+
+def test_one_rank_through_rccl():
+    """The process-group path of bench.py on the real backend: INFLX_BENCH_FORCE_DIST=1 brings up a one-rank `nccl` group (RCCL), so
+    that the barrier, the MIN all-reduce that agrees on the block size, the MAX over ranks, the gather of the per-rank kernel times
+    and of the device names, and the summary all-reduces have all run on device tensors through RCCL before any multi-GPU job."""
+    env = dict(os.environ, INFLX_BENCH_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    proc = subprocess.run([sys.executable, "bench.py", "--grid", "2048", "--steps", "3", "--warmup", "1", "--rows-per-gpu", "2", "--no-extras", "--no-cpu-baseline"],
+                          cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    line = _line(proc)
+    assert line["comm_backend"] == "nccl" and line["rccl_ranks"] == 1 and line["ranks"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["parameter_rows_per_gpu"] == 2 and line["config"]["rows_per_gpu_requested"] == 2
+    assert len(line["devices"]) == 1 and line["devices"][0].startswith("cuda:0 ")
+    assert line["summary_sweep"]["non_nan"][1] == 2 * 2048 * 2048
+    assert abs(line["value"] - 2 * 2048 * 2048 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-9
