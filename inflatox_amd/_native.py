@@ -271,7 +271,11 @@ class InflatoxDevLib:
         if x.ndim != 2 or x.shape[1] != 2:
             raise InflatoxShapeError(f"trajectory array should have shape (n,2) (got {x.shape})")
         k = OP_WIDTH[op]
-        out = np.zeros((x.shape[0], k) if k > 1 else (x.shape[0],))
+        from ._result_pool import result_array
+
+        shape = (x.shape[0], k) if k > 1 else (x.shape[0],)
+        # long trajectories: recycled page-resident memory (every element is written by the sweep); short ones: a plain array
+        out = result_array(shape) if x.shape[0] * k * 8 >= (1 << 20) else np.zeros(shape)
         _check(self._lib.inflx_sweep_on_trajectory(self._h, op, _ptr(p), p.size, _ptr(x), x.shape[0], _ptr(out), int(bool(progress)), int(threads)))
         return out
 

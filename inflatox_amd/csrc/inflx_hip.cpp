@@ -1831,6 +1831,9 @@ int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_
   void* params[] = {&a};
   const size_t gx = (n + m->info.tile_cols - 1) / m->info.tile_cols;
   HIP_TRY(hipModuleLaunchKernel(m->traj[op], (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
+  // a long trajectory's result lands in a fresh host array: make its pages resident (huge pages, several threads) while the
+  // kernel runs, instead of letting the copy fault them in one by one (14 GB/s against 50, section 5 of DESIGN.md)
+  if (out_bytes >= (size_t(4) << 20)) prefault_range(reinterpret_cast<char*>(out), out_bytes);
   HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   return INFLX_OK;
