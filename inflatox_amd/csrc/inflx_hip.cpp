@@ -1647,6 +1647,8 @@ class Reporter {
   }
   Reporter(const Reporter&) = delete;
   Reporter& operator=(const Reporter&) = delete;
+  // is anybody reading the counter?  (no: the pipelines are not asked to keep it -- no slice events, no host-side chunk waits)
+  bool active() const { return th_.joinable(); }
 
  private:
   void run() {
@@ -1682,7 +1684,7 @@ int grid_entry(inflx_model* m, int op, const double* p, size_t n_p, double* out,
   pr.total = (uint64_t)N0 * N1 * kOpBytes[op];
   {
     Reporter reporter(&pr, (double)N0 * (double)N1, progress != 0);
-    rc = sweep_host_impl(m, op, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, 0.0, HostDest(), progress ? &pr : nullptr);
+    rc = sweep_host_impl(m, op, p, 1, n_p, out, ss, N0, N1, 0, N0, INFLX_AOS, 0.0, HostDest(), reporter.active() ? &pr : nullptr);
   }
   if (rc) return rc;
   if (progress) {
@@ -1928,7 +1930,7 @@ int inflx_sweep_host_multi(inflx_multi* mm, int op, const double* p, size_t P, s
   pr.total = (uint64_t)P * N0 * N1 * kOpBytes[op];
   {
     Reporter reporter(&pr, (double)P * (double)N0 * (double)N1, progress != 0);
-    Progress* sink = progress ? &pr : nullptr;
+    Progress* sink = reporter.active() ? &pr : nullptr;
     rc = run_parts(world, [&](size_t k) -> int {
       const ShardPlan s = shard_plan(P, N0, world, k);
       if (s.p_count == 0 || s.row_count == 0) return INFLX_OK;
