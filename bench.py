@@ -334,6 +334,7 @@ def end_to_end(workloads, np, model: str, n: int, device: int):
     warm = timed(lambda: al.complete_analysis(spec.args, *spec.extent, n, n, progress=False), 3)
     lean = timed(lambda: al.complete_analysis(spec.args, *spec.extent, n, n, progress=False, broadcast_views=True), 5)
     dev = timed(lambda: al.complete_analysis_device(spec.args, *spec.extent, n, n), 5)
+    small = timed(lambda: al.complete_analysis(spec.args, *spec.extent, 256, 256, progress=False), 20)
     return {
         "workload": f"GeneralisedAL.complete_analysis, {model} {n}x{n} -> six arrays of the caller (never part of `value`)",
         # the reference-compatible default, first call / repeated calls
@@ -344,6 +345,10 @@ def end_to_end(workloads, np, model: str, n: int, device: int):
         "default_warm": rec(warm, "best of 3 repeated calls: result memory recycled by the result pool, same host-side broadcast fill"),
         "broadcast_views": rec(lean, "opt-in broadcast_views=True, best of 5: one evaluated line copied, six read-only stride-0 views (only where the model ignores one field)"),
         "device_resident": rec(dev, "complete_analysis_device, best of 5 incl. synchronisation: six torch views of a device tensor (DLPack / __cuda_array_interface__), nothing crosses PCIe"),
+        # BASELINE configs[0] as written: the 256 x 256 grid through the same front-end call (3.1 MB: below the host-fill threshold,
+        # the whole result crosses PCIe); cpu_baseline.configs0_256x256 is the CPU port on the same grid
+        "configs0_256x256": {"what": "the default call on BASELINE configs[0]'s 256x256 grid, best of 20 (launch + copy latency, not throughput)",
+                             "ms": small * 1e3, "points_per_s": 256 * 256 / small},
     }
 
 

@@ -187,19 +187,55 @@ class GeneralisedAL(InflationCondition):
         N_x1: int = 1_000,
         layout: str = "aos",
     ) -> np.ndarray:
-        """Extension: ``args`` is (P, n_parameters); returns (P, N_x0, N_x1, 6) (``layout='aos'``)
-        or (P, 6, N_x0, N_x1) (``'soa'``) -- the outer parameter axis of the sweep in one call."""
+        """Extension: the outer parameter axes of the sweep in one call.  ``args`` is (P, n_parameters) -- or an N-D
+        parameter grid (P_1, ..., P_k, n_parameters), e.g. from :meth:`parameter_grid` --; returns (P, N_x0, N_x1, 6)
+        resp. (P_1, ..., P_k, N_x0, N_x1, 6) (``layout='aos'``), or (..., 6, N_x0, N_x1) (``'soa'``).  The parameter axes are
+        swept as one flat outermost axis (C order); with ``devices=...`` that axis is what the devices share."""
         lay = {"aos": _native.LAYOUT_AOS, "soa": _native.LAYOUT_SOA}[layout]
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
-        return (self.multi or self.dylib).sweep_host(_native.OP_COMPLETE, np.atleast_2d(np.asarray(args, dtype=np.float64)), ss, N_x0, N_x1, layout=lay)
+        rows = np.atleast_2d(np.asarray(args, dtype=np.float64))
+        lead = rows.shape[:-1]
+        out = (self.multi or self.dylib).sweep_host(_native.OP_COMPLETE, rows.reshape(-1, rows.shape[-1]), ss, N_x0, N_x1, layout=lay)
+        return out.reshape(lead + out.shape[1:])
+
+    def parameter_grid(self, args, axes: dict) -> np.ndarray:
+        """Extension: the N-D parameter grid of a scan.  ``args`` is the base parameter vector, ``axes`` maps parameters --
+        a position in ``args``, a sympy symbol of the model or its printed name (``artifact.symbol_dictionary``) -- to
+        1-D arrays of values; returns (len_1, ..., len_k, n_parameters) in the order of ``axes``, every other parameter held
+        at its base value: the ``args`` of :meth:`complete_analysis_batch` / :meth:`complete_analysis_summary`."""
+        base = np.asarray(args, dtype=np.float64).reshape(-1)
+        if base.size != self.artifact.n_parameters:
+            raise _native.InflatoxShapeError(f"expected {self.artifact.n_parameters} parameters (got {base.size})")
+        slots, values = [], []
+        for key, vals in axes.items():
+            if isinstance(key, (int, np.integer)):
+                k = int(key)
+            else:
+                name = key if isinstance(key, str) else self.artifact.symbol_printer._print_Symbol(key)
+                target = self.artifact.symbol_dictionary.get(name, "")
+                if not target.startswith("args["):
+                    raise KeyError(f"{key!r} is not a parameter of this model (parameters: {[n for n, t in self.artifact.symbol_dictionary.items() if t.startswith('args[')]})")
+                k = int(target[5:-1])
+            if not 0 <= k < base.size or k in slots:
+                raise KeyError(f"parameter position {k} out of range or named twice")
+            slots.append(k)
+            values.append(np.asarray(vals, dtype=np.float64).reshape(-1))
+        shape = tuple(v.size for v in values)
+        grid = np.empty(shape + (base.size,))
+        grid[...] = base
+        for d, (k, v) in enumerate(zip(slots, values)):
+            grid[..., k] = v.reshape((1,) * d + (-1,) + (1,) * (len(shape) - d - 1))
+        return grid
 
     def complete_analysis_summary(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=1_000, N_x1=1_000) -> dict:
         """Extension: NaN-ignoring minimum, maximum and non-NaN count of the six quantities over the sweep,
         reduced on the GPU inside the sweep kernels -- what ``np.nanmin/np.nanmax`` over the six arrays of
         :meth:`complete_analysis` would give (the reference's tests do exactly that, tests/test_doc.py:58),
-        without materialising or copying the arrays.  ``args`` may be (P, n_parameters)."""
+        without materialising or copying the arrays.  ``args`` may be (P, n_parameters) or an N-D parameter grid
+        (..., n_parameters); the summary covers all of its rows."""
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
-        return (self.multi or self.dylib).sweep_stats(args, ss, N_x0, N_x1)
+        rows = np.asarray(args, dtype=np.float64)
+        return (self.multi or self.dylib).sweep_stats(rows.reshape(-1, rows.shape[-1]) if rows.ndim > 2 else rows, ss, N_x0, N_x1)
 
     # ---- single-quantity sweeps (reference :310-475) ---------------------------------------------
     def _single(self, fn, args, x0_start, x0_stop, x1_start, x1_stop, N_x0, N_x1, progress, threads):

@@ -171,3 +171,69 @@ def test_device_resident_multi_sweep_and_peer_all_gather(name, gpu_lib):
                     assert np.array_equal(b.cpu().numpy(), ref, equal_nan=True), (devices, P, n0, n1, pl)
         with pytest.raises(gpu_lib.InflatoxShapeError):
             multi.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:2], [t.data_ptr() for t in full], 8, spec.extent, 8, 8)
+
+
+def test_parameter_grid_is_the_outer_product_of_its_axes():
+    """north_star's "2D field-space x N-D parameter grid": parameter_grid builds the (len_1, ..., len_k, n_p) rows of a scan from a
+    base vector and named axes (position, printed name or symbol); no device is needed for that."""
+    import sympy
+
+    import workloads
+    from inflatox_amd.consistency_conditions import GeneralisedAL
+
+    spec, art = workloads.artifact_for("hyperbolic")
+    al = GeneralisedAL.__new__(GeneralisedAL)
+    al.artifact = art
+    names = [n for n, t in sorted(art.symbol_dictionary.items(), key=lambda kv: kv[1]) if t.startswith("args[")]
+    assert names == ["m", "φ0", "L"]  # README order (tests/golden/symbols.json)
+    ms, Ls = np.array([0.5, 1.0]), np.linspace(0.2, 2.0, 5)
+    grid = al.parameter_grid(spec.args, {"m": ms, sympy.Symbol("L"): Ls})
+    assert grid.shape == (2, 5, 3)
+    for i in range(2):
+        for j in range(5):
+            assert np.array_equal(grid[i, j], [ms[i], spec.args[1], Ls[j]])
+    assert np.array_equal(al.parameter_grid(spec.args, {2: Ls})[:, 2], Ls) and al.parameter_grid(spec.args, {}).shape == (3,)
+    with pytest.raises(KeyError):
+        al.parameter_grid(spec.args, {"θ": Ls})  # a field, not a parameter
+    with pytest.raises(KeyError):
+        al.parameter_grid(spec.args, {"m": ms, 0: ms})  # the same parameter twice
+    with pytest.raises(Exception, match="expected 3 parameters"):
+        al.parameter_grid(spec.args[:2], {"m": ms})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,axes", [("hyperbolic", {"m": [0.5, 1.0], "L": [0.2, 1.1, 2.0]}), ("doc", {0: [0.5, 1.0, 2.0, 3.0]})])
+def test_nd_parameter_grid_sweep_equals_one_call_per_grid_node(name, axes, gpu_lib):
+    """complete_analysis_batch over an N-D parameter grid = complete_analysis at every node of it, bit for bit, on one device and
+    on two handles; the fused summary covers all nodes."""
+    import workloads
+    from inflatox_amd.consistency_conditions import GeneralisedAL, InflationCondition
+
+    spec, art = workloads.artifact_for(name)
+
+    def make(**kw):
+        al = GeneralisedAL.__new__(GeneralisedAL)
+        InflationCondition.__init__(al, art, validate_basis=False, **kw)
+        return al
+
+    one, two = make(), make(devices=[0, 0])
+    grid = one.parameter_grid(spec.args, axes)
+    lead = grid.shape[:-1]
+    n0, n1 = 37, 129
+    res = one.complete_analysis_batch(grid, *spec.extent, n0, n1)
+    assert res.shape == lead + (n0, n1, 6) and res.flags.c_contiguous
+    planes = one.complete_analysis_batch(grid, *spec.extent, n0, n1, layout="soa")
+    assert planes.shape == lead + (6, n0, n1)
+    assert np.array_equal(two.complete_analysis_batch(grid, *spec.extent, n0, n1), res, equal_nan=True)
+    for node in np.ndindex(*lead):
+        ref = one.complete_analysis(grid[node], *spec.extent, n0, n1, progress=False)
+        for k in range(6):
+            assert np.array_equal(res[node][:, :, k], ref[k], equal_nan=True) and np.array_equal(planes[node][k], ref[k], equal_nan=True)
+    summary = one.complete_analysis_summary(grid, *spec.extent, n0, n1)
+    with np.errstate(all="ignore"):
+        for k in range(6):
+            vals = res[..., k]
+            count = int(np.count_nonzero(~np.isnan(vals)))
+            assert summary["count"][k] == count
+            if count:
+                assert summary["min"][k] == np.nanmin(vals) and summary["max"][k] == np.nanmax(vals)
