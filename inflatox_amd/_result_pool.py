@@ -9,8 +9,14 @@ result dies, its (page-resident) buffer goes back to the pool instead of to the 
 size is built on it.  The arrays are ordinary writeable numpy arrays; nothing is shared between live results; the sweep
 writes every element, so no zeroing is needed.
 
-``INFLX_RESULT_POOL_MB`` (default 1024) bounds the memory the pool keeps; 0 switches it off (plain ``np.zeros``).
-Arrays above half of the bound are never pooled.  When a returning buffer does not fit, the buffers that have been lying
+Large results gain the most: dropping a 768 MiB result (4096 x 4096) costs 37-47 ms on a GPU box's host -- the kernel tears the
+mapping down through the GPU driver's MMU notifiers, the pages having been the target of a DMA -- against 17 ms for the call that
+produced it, and filling fresh pages costs another 2.5 ms (scripts/big_result_probe.py).
+
+``INFLX_RESULT_POOL_MB`` bounds the memory the pool keeps (default: an eighth of the machine's -- or the cgroup's -- memory, at
+least 1 GiB and at most 16 GiB: an 8192 x 8192 result of 3.2 GB is recycled on any host a GPU sits in); 0 switches the pool off
+(plain ``np.zeros``).  Arrays above half of the bound are never pooled.  ``release()`` hands everything the pool holds back to the
+system.  When a returning buffer does not fit, the buffers that have been lying
 in the pool longest are released first (a scan that moves on to another grid size does not stay stuck with the old one).
 
 Locking: the finalizer of a result array can run at any point at which the garbage collector runs -- also while this
@@ -30,7 +36,25 @@ import weakref
 
 import numpy as np
 
-_LIMIT = max(0, int(os.environ.get("INFLX_RESULT_POOL_MB", "1024"))) << 20
+
+
+def _default_limit() -> int:
+    env = os.environ.get("INFLX_RESULT_POOL_MB")
+    if env is not None:
+        return max(0, int(env)) << 20
+    try:
+        memory = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
+    except (ValueError, OSError):
+        memory = 8 << 30
+    try:  # a container's share of it (cgroup v2)
+        with open("/sys/fs/cgroup/memory.max") as fh:
+            memory = min(memory, int(fh.read().strip()))
+    except (OSError, ValueError):  # no cgroup limit ("max") or no cgroup v2
+        pass
+    return max(1 << 30, min(memory // 8, 16 << 30))
+
+
+_LIMIT = _default_limit()
 _PER_SIZE = 4
 
 _lock = threading.RLock()
@@ -103,6 +127,18 @@ def result_array(shape, dtype=np.float64) -> np.ndarray:
     owner = np.frombuffer(buf, dtype=dtype, count=count)  # every view's .base collapses to this array
     weakref.finalize(owner, _give_back, buf, nbytes)
     return owner.reshape(shape)
+
+
+def release() -> int:
+    """Hand every buffer the pool holds back to the system; returns the number of bytes released.  (Live results are not
+    touched; their buffers come back to the pool when they die, as always.)"""
+    global _held
+    with _lock:
+        _drain()
+        freed = _held
+        _free.clear()
+        _held = 0
+    return freed
 
 
 def held_bytes() -> int:

@@ -87,3 +87,24 @@ def test_stale_sizes_make_room_for_new_ones(monkeypatch):
     assert pool.held_bytes() >= before - 100 * 100 * 48  # at most one old buffer went
     again = pool.result_array((100, 101, 6))
     assert _addr(again) == addr  # the new size is pooled although the pool was full of the old one
+
+
+def test_default_bound_follows_the_machine_and_release_empties_the_pool(monkeypatch):
+    """Large results are where recycling pays most (dropping a 768 MiB result costs more than the sweep that made it): the default
+    bound scales with the memory of the machine / cgroup, between 1 and 16 GiB; INFLX_RESULT_POOL_MB overrides; release() returns
+    everything."""
+    monkeypatch.delenv("INFLX_RESULT_POOL_MB", raising=False)
+    assert (1 << 30) <= pool._default_limit() <= (16 << 30)
+    monkeypatch.setenv("INFLX_RESULT_POOL_MB", "3")
+    assert pool._default_limit() == 3 << 20
+    monkeypatch.setenv("INFLX_RESULT_POOL_MB", "0")
+    assert pool._default_limit() == 0
+    a = pool.result_array((77, 13, 6))
+    addr = _addr(a)
+    del a
+    gc.collect()
+    assert pool.held_bytes() >= 77 * 13 * 48
+    assert pool.release() >= 77 * 13 * 48 and pool.held_bytes() == 0
+    b = pool.result_array((77, 13, 6))  # a fresh mapping, usable as ever
+    b[...] = 2.0
+    assert float(b.sum()) == 2.0 * 77 * 13 * 6 and (addr or True)
