@@ -204,6 +204,9 @@ struct inflx_model {
   hipEvent_t stage_free[2] = {nullptr, nullptr};   // the tile kernel that last read buffer b finished
   bool stage_used[2] = {false, false};
   unsigned stage_turn = 0;
+  // decided per call by evaluates_on_side_stream, read by launch_tiles: a tile sweep that is ONE launch builds its tables on
+  // the caller's stream, in front of the tile kernel (no second stream, no event between the two)
+  bool tables_on_callers_stream = false;
   hipFunction_t tile_stats = nullptr, tile_stats_nostore = nullptr, rowvals_stats = nullptr;
   double* d_stats = nullptr;  // 18 x 8 bytes: min[6], max[6], count[6]
   // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
@@ -369,19 +372,6 @@ bool takes_col_stream(const inflx_model* m, int op, int layout, size_t P, size_t
   if (planes) return N1 % 2 == 0;
   return (K * N1) % 2 == 0;
 }
-// Which stream are the parameters uploaded on?  The first kernel that reads them runs on the side stream for the two
-// broadcast paths (per-row / per-column evaluation) and for the tile path (stage tables); only the fallback row kernel
-// of row-only models reads them on the caller's stream first.
-bool evaluates_on_side_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
-  if (takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1)) return true;
-  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
-  return !row_uniform;  // tile path
-}
-// ... and on which stream does the LAST kernel that reads them run?  The tile kernels read the parameter rows too
-// (the point stage uses args[k]), after the table kernel; on the broadcast paths the store streams do not.
-bool last_reader_is_callers_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
-  return !(takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1));
-}
 
 // Geometry of the two-launch row-broadcast path for one call (shared by launch_grid and inflx_sweep_plan).
 struct RowStreamPlan {
@@ -408,6 +398,60 @@ RowStreamPlan row_stream_plan(const inflx_model* m, int op, int layout, size_t P
   return r;
 }
 
+// Parameter rows per table batch of the column-broadcast path (images of at most 64 MiB, grid.z of the copy stream).
+size_t col_stream_batch(int op, int layout, size_t P, size_t N1) {
+  const size_t K = kOpWidth[op];
+  const size_t images_per_p = (layout == INFLX_SOA || K == 1) ? K : 1;
+  size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(K * N1 * 8, 1)));
+  return std::min<size_t>(batch, 65535 / images_per_p);
+}
+
+// The tile path as a sequence of launches: parameter rows in batches whose tables fit 1 GiB, grid rows in slabs of at most
+// 65535 tiles (grid.y).
+struct TilePlan {
+  size_t rows_per_launch, pbatch;
+};
+TilePlan tile_plan(const inflx_model* m, size_t P, size_t N1, size_t row_count) {
+  const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nc = std::max<size_t>(m->info.n_col, 1);
+  const size_t nr = (std::max<size_t>(m->info.n_row, 1) + 1) & ~size_t(1);  // even stride of a row's values (kNRs of the kernels)
+  TilePlan t;
+  t.rows_per_launch = size_t(65535) * m->info.tile_rows;
+  const size_t per_p = nu + std::min(t.rows_per_launch, row_count) * nr + nc * N1;  // doubles per parameter row
+  t.pbatch = std::max<size_t>(1, std::min<size_t>(P, (size_t(1) << 27) / std::max<size_t>(per_p, 1)));
+  return t;
+}
+// Which stream are the parameters uploaded on?  The first kernel that reads them runs on the side stream for the two
+// broadcast paths (per-row / per-column evaluation) and for the tile path (stage tables) -- unless the sweep is a single
+// pair of launches enqueued alone (below) --; the fallback row kernel of row-only models reads them on the caller's stream.
+// `alone`: the sweep is enqueued on its own and waited for (a host-result call that is one launch + one copy).  Sweeps that may be
+// enqueued back to back -- the asynchronous device-result entry points, the chunk pipeline -- keep the tables on the side stream, where
+// the table kernel of sweep k+1 overlaps the tile kernel of sweep k like the launches of a multi-launch sweep do.
+bool evaluates_on_side_stream(inflx_model* m, int op, int layout, size_t P, size_t N1, size_t row_count, bool alone = false) {
+  m->tables_on_callers_stream = false;
+  // the broadcast paths: per-row / per-column evaluation, then the store stream; one table batch = one pair of launches
+  if (takes_row_stream(m, op, layout, P, N1)) {
+    m->tables_on_callers_stream = alone && P <= row_stream_plan(m, op, layout, P, N1, row_count).batch;
+    return !m->tables_on_callers_stream;
+  }
+  if (takes_col_stream(m, op, layout, P, N1)) {
+    m->tables_on_callers_stream = alone && P <= col_stream_batch(op, layout, P, N1);
+    return !m->tables_on_callers_stream;
+  }
+  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
+  if (row_uniform) return false;
+  // tile path: tables, then tile kernel.  Several launches: the tables of launch k+1 are built on the side stream while the tile
+  // kernel of launch k runs.  A single launch that nothing follows has nothing to overlap with, and the hop between two streams
+  // (event record, wait, a second doorbell) is 10-15 us of the ~60 us a small sweep takes: it runs on the caller's stream alone.
+  const TilePlan t = tile_plan(m, P, N1, row_count);
+  m->tables_on_callers_stream = alone && P <= t.pbatch && row_count <= t.rows_per_launch;
+  return !m->tables_on_callers_stream;
+}
+// ... and on which stream does the LAST kernel that reads them run?  The tile kernels read the parameter rows too
+// (the point stage uses args[k]), after the table kernel; on the broadcast paths the store streams do not.
+bool last_reader_is_callers_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
+  return !(takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1));
+}
+
 // (in-pipeline timing of the dominant kernel, see inflx_model::probe) -- no-ops unless a probe is armed and has pairs left
 hipError_t probe_begin(inflx_model* m, hipStream_t s) {
   if (!m->probe) return hipSuccess;
@@ -430,6 +474,7 @@ hipError_t probe_end(inflx_model* m, hipStream_t s) {
 int launch_row_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, int layout, hipStream_t s, int what, double* d_stats) {
   void* params[] = {&a};
   const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
+  hipStream_t ev = m->tables_on_callers_stream ? s : m->side;  // (decided with the stream of the parameter upload, evaluates_on_side_stream)
   const RowStreamPlan plan = row_stream_plan(m, op, layout, P, N1, row_count);
   const size_t cpr = plan.cpr, replicas = plan.replicas, batch = plan.batch;
   if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
@@ -452,15 +497,16 @@ int launch_row_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_
     a.table_replicas = (uint32_t)replicas;
     a.stream_planes = (uint32_t)K;
     if (what != 2) {
-      // per-row evaluation on the side stream, as soon as the previous reader of this table is done
-      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
+      // per-row evaluation on the side stream (on the caller's for a single pair of launches enqueued alone), as soon as the
+      // previous reader of this table is done
+      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(ev, m->table_free[b], 0));
       HIP_TRY(hipModuleLaunchKernel(d_stats ? m->rowvals_stats : m->rowvals[op], (unsigned)((row_count + 63) / 64), (unsigned)pb, 1, 64, 1, 1, 0,
-                                    m->side, params, nullptr));
-      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+                                    ev, params, nullptr));
+      if (ev != s) HIP_TRY(hipEventRecord(m->table_ready[b], ev));
       m->table_turn++;
     }
     if (what != 1 && store) {
-      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+      if (ev != s) HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
       // grid.y is limited to 65535, longer slabs take several launches
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
@@ -482,14 +528,14 @@ int launch_row_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_
 int launch_col_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, int layout, hipStream_t s, int what, double* d_stats) {
   void* params[] = {&a};
   const size_t K = kOpWidth[op];
+  hipStream_t ev = m->tables_on_callers_stream ? s : m->side;
   const bool planes = layout == INFLX_SOA || K == 1;
   const size_t images_per_p = planes ? K : 1;
   const size_t units = (planes ? N1 : K * N1) / 2;  // 16-byte units per output row
   const size_t cpr = (units + m->info.tile_cols - 1) / m->info.tile_cols;
   if (cpr > 0x7fffffffULL) return fail(INFLX_ERR_SHAPE, "grid rows too long for one launch");
   const size_t image_doubles = K * N1;  // per parameter row
-  size_t batch = std::max<size_t>(1, std::min<size_t>(P, (size_t(64) << 20) / std::max<size_t>(image_doubles * 8, 1)));
-  batch = std::min<size_t>(batch, 65535 / images_per_p);
+  const size_t batch = col_stream_batch(op, layout, P, N1);
   if (what == 2 && batch < P)
     return fail(INFLX_ERR_ARG, "dominant_only timing needs the parameter rows to fit one table batch (%zu rows here, got %zu)", batch, P);
   const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols;
@@ -505,14 +551,14 @@ int launch_col_stream(inflx_model* m, int op, InflxSweepArgs a, const double* d_
     a.row_table = store ? m->d_row_table[b] : nullptr;
     a.stream_units = units;
     if (what != 2) {
-      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->table_free[b], 0));
-      HIP_TRY(hipModuleLaunchKernel(d_stats ? m->colvals_stats : m->colvals[op], (unsigned)gx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params,
+      if (m->table_used[b]) HIP_TRY(hipStreamWaitEvent(ev, m->table_free[b], 0));
+      HIP_TRY(hipModuleLaunchKernel(d_stats ? m->colvals_stats : m->colvals[op], (unsigned)gx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, ev, params,
                                     nullptr));
-      HIP_TRY(hipEventRecord(m->table_ready[b], m->side));
+      if (ev != s) HIP_TRY(hipEventRecord(m->table_ready[b], ev));
       m->table_turn++;
     }
     if (what != 1 && store) {
-      HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
+      if (ev != s) HIP_TRY(hipStreamWaitEvent(s, m->table_ready[b], 0));
       for (size_t r0 = 0; r0 < row_count; r0 += 65535) {
         a.stream_row0 = (uint32_t)r0;
         const size_t nr = std::min<size_t>(65535, row_count - r0);
@@ -551,6 +597,8 @@ int launch_rows_fallback(inflx_model* m, int op, InflxSweepArgs a, size_t P, siz
 // so that in a sequence of launches the tables of launch n+1 are evaluated while the tile kernel of launch n runs.
 // grid.y is limited to 65535 tiles: a taller slab takes several launches, each with tables of its own; parameter rows
 // are batched so that one set of tables stays below 1 GiB.
+constexpr size_t kSmallLaunchWorkgroups = 256;  // a tile launch with fewer workgroups than the chip has CUs gets lower tiles
+
 int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
                  double* d_stats) {
   void* params[] = {&a};
@@ -560,10 +608,10 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
   hipFunction_t f = d_stats ? (d_out ? m->tile_stats : m->tile_stats_nostore) : m->tile[op];
   const size_t nu = std::max<size_t>(m->info.n_uniform, 1), nc = std::max<size_t>(m->info.n_col, 1);
   const size_t nr = (std::max<size_t>(m->info.n_row, 1) + 1) & ~size_t(1);  // even stride of a row's values (kNRs of the kernels)
-  const size_t rows_per_launch = size_t(65535) * m->info.tile_rows;
-  const size_t slab_max = std::min(rows_per_launch, row_count);
-  const size_t per_p = nu + slab_max * nr + nc * N1;  // doubles per parameter row
-  const size_t pbatch = std::max<size_t>(1, std::min<size_t>(P, (size_t(1) << 27) / std::max<size_t>(per_p, 1)));
+  const TilePlan plan = tile_plan(m, P, N1, row_count);
+  const size_t rows_per_launch = plan.rows_per_launch, pbatch = plan.pbatch;
+  // (the entry point decided where the tables are built when it chose the stream of the parameter upload: the two must agree)
+  hipStream_t tables = m->tables_on_callers_stream ? s : m->side;
   for (size_t p0 = 0; p0 < P; p0 += pbatch) {
     const size_t pb = std::min(pbatch, P - p0);
     a.params = d_params + p0 * m->n_par;
@@ -586,14 +634,24 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
       a.stream_row0 = (uint32_t)r0;
       a.stream_units = slab;
       // tables on the side stream, as soon as the tile kernel that read this buffer two launches ago is done ...
-      if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(m->side, m->stage_free[b], 0));
+      if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(tables, m->stage_free[b], 0));
       const size_t tx = (std::max(slab, N1) + m->info.tile_cols - 1) / m->info.tile_cols;
-      HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, m->side, params, nullptr));
-      HIP_TRY(hipEventRecord(m->stage_ready[b], m->side));
+      HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, tables, params, nullptr));
       m->stage_turn++;
       // ... and the tile kernel on the caller's stream behind them
-      HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
-      const size_t gy = (slab + m->info.tile_rows - 1) / m->info.tile_rows;
+      if (tables != s) {
+        HIP_TRY(hipEventRecord(m->stage_ready[b], tables));
+        HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
+      }
+      // Tile height of this launch.  The kernels walk a tile's rows one after the other: a grid with fewer full-height tiles
+      // than the chip has CUs (1000 x 1000: 128, 256 x 256: 8) would leave most of it idle for the time of 32 rows, so such a
+      // launch is cut into lower tiles -- about two workgroups per CU, one round whatever the occupancy -- and every
+      // wavefront has a quarter (an eighth ...) of the rows to walk.  Larger grids keep the full height and its amortisation
+      // of the per-tile prologue.
+      size_t th = m->info.tile_rows;
+      if (gx * ((slab + th - 1) / th) * pb < kSmallLaunchWorkgroups) th = std::min(th, std::max<size_t>(2, (gx * slab * pb + 2 * kSmallLaunchWorkgroups - 1) / (2 * kSmallLaunchWorkgroups)));
+      a.tile_rows = (uint32_t)th;
+      const size_t gy = (slab + th - 1) / th;
       HIP_TRY(probe_begin(m, s));
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
       HIP_TRY(probe_end(m, s));
@@ -958,7 +1016,7 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
   // `up`: the stream of the first kernel of the sweep (parameters and the initial summary are ordered before it);
   // `eval`: the stream of the kernels that accumulate (the per-row / per-column evaluation of the broadcast paths on the
   // side stream, the tile kernels on the caller's)
-  hipStream_t up = evaluates_on_side_stream(m, op, INFLX_AOS, P, N1) ? m->side : s;
+  hipStream_t up = evaluates_on_side_stream(m, op, INFLX_AOS, P, N1, row_count) ? m->side : s;
   hipStream_t eval = last_reader_is_callers_stream(m, op, INFLX_AOS, P, N1) ? s : m->side;
   if (!m->d_stats) HIP_TRY(hipMalloc(reinterpret_cast<void**>(&m->d_stats), 18 * sizeof(double)));
   inflx_summary init;
@@ -1005,7 +1063,7 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
   // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
   // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
-  hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1) ? m->side : s;
+  hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1, row_count) ? m->side : s;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
@@ -1415,7 +1473,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   }
   // the stream of the kernels that read the parameters: decided by the P the launches below really see (the
   // whole-result path launches all P rows at once, the chunk pipeline one parameter row at a time)
-  hipStream_t reader = evaluates_on_side_stream(m, op, layout, whole ? P : 1, N1) ? m->side : m->stream;
+  hipStream_t reader = evaluates_on_side_stream(m, op, layout, whole ? P : 1, N1, row_count, /*alone=*/whole) ? m->side : m->stream;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, reader, &d_params))) return rc;
   if (whole) {

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 15u
+#define INFLX_KERNEL_ABI 16u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -58,6 +58,11 @@ struct InflxSweepArgs {
   // tile kernels (some value depends on x[1]): row_table holds the stage tables inflx_stage_tables wrote for this launch,
   //   U[P][max(NU,1)] | R[P][slab_rows][NRs] | C[P][max(NC,1)][N1]   (doubles; NRs = max(NR,1) rounded up to even),
   // the slab being grid rows [stream_row0, stream_row0 + stream_units) relative to row_begin (stream_units = slab_rows here)
+  // tile kernels: grid rows per workgroup tile of THIS launch, 1 ... InflxKernelInfo::tile_rows.  Large grids use the full
+  // height; a grid with fewer full-height tiles than the chip has wavefront slots is cut into lower tiles, so that a
+  // 256 x 256 or 1000 x 1000 sweep is not eight (128) workgroups walking 32 rows each one after the other
+  uint32_t tile_rows;
+  uint32_t reserved0;
 };
 
 // Launch arguments of the on-trajectory kernels: n explicit points (x0, x1) per launch

@@ -321,9 +321,10 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const uint64_t j = col0 + tid;
   const double x1 = inflx_coord(j, a.dx1, a.x1a);
   // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
-  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * kTileRows;
+  const unsigned tile_rows = a.tile_rows;  // height of this launch's tiles (<= kTileRows; lower for small grids)
+  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * tile_rows;
   const uint64_t left = a.row_count - row0;
-  const int nrows = left < (uint64_t)kTileRows ? (int)left : kTileRows;
+  const int nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
 #ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE  // (A/B experiment only: the round-1 prologue, every workgroup evaluates its own stage values)
 #if INFLX_U_IN_LDS
   __shared__ __attribute__((aligned(16))) double U[kNU];
@@ -353,7 +354,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #pragma unroll
   for (int k = 0; k < kNC; ++k) C[k] = j < a.N1 ? ctab[(uint64_t)k * a.N1 + j] : 0.0;
   {
-    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * kTileRows * kNRs;
+    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * tile_rows * kNRs;
     double* dst = &Rs[0][0];
     for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
   }
