@@ -1370,6 +1370,7 @@ void stream_copy(char* dst, const char* src, size_t bytes) {
 template <typename F>
 void parallel_blocks(size_t n, size_t bytes_per_item, F fill) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  if (n == 0) return;
   size_t nthreads = std::min<size_t>(std::min(host_fill_threads(), hw), n);
   nthreads = std::min<size_t>(nthreads, std::max<size_t>(1, n * bytes_per_item / (size_t(4) << 20)));  // at least 4 MiB per thread
   std::vector<std::thread> pool;

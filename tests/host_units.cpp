@@ -1,0 +1,142 @@
+// Unit checks of the HOST-side helpers of libinflx_hip.so that touch memory by hand -- the streaming-store fill of broadcast
+// results, the span / stripe arithmetic of the device-to-host transfer, the page-touching helpers, the partition of a
+// multi-device sweep, the progress reporter -- built with AddressSanitizer + UBSan on the CPU (tests/test_cabi.py).  No GPU
+// is needed: nothing here calls into HIP.  The translation unit includes the library source itself, so that the functions
+// of its unnamed namespace are reachable.
+#include "../inflatox_amd/csrc/inflx_hip.cpp"
+
+#include <cassert>
+
+#define CHECK(cond)                                                          \
+  do {                                                                       \
+    if (!(cond)) {                                                           \
+      fprintf(stderr, "host_units: %s failed (line %d)\n", #cond, __LINE__); \
+      return 1;                                                              \
+    }                                                                        \
+  } while (0)
+
+static uint64_t g_state = 0x1234567ull;
+static uint64_t rnd() { return (uint64_t)(unit_random(g_state) * 9007199254740992.0); }
+
+int main() {
+  // ---- repeat_record: every record size the sweeps have (8 ... 48 bytes), every destination alignment, short and long runs
+  for (size_t rec_bytes : {8, 16, 24, 40, 48}) {
+    for (int trial = 0; trial < 200; ++trial) {
+      const size_t n = trial < 20 ? (size_t)trial : (size_t)(rnd() % 3000);
+      const size_t shift = 8 * (rnd() % 8);  // results are arrays of doubles: 8-byte aligned at least
+      std::vector<char> buf(n * rec_bytes + 64 + 64, (char)0xEE);
+      char* base = buf.data();
+      base += (64 - (reinterpret_cast<uintptr_t>(base) & 63)) & 63;
+      char* dst = base + shift;
+      char rec[48];
+      for (size_t k = 0; k < rec_bytes; ++k) rec[k] = (char)(rnd() & 0xff);
+      repeat_record(dst, rec, rec_bytes, n);
+      _mm_sfence();
+      for (size_t q = 0; q < n; ++q) CHECK(memcmp(dst + q * rec_bytes, rec, rec_bytes) == 0);
+      CHECK((unsigned char)dst[n * rec_bytes] == 0xEE);  // nothing written behind the run
+      if (shift) CHECK((unsigned char)dst[-1] == 0xEE);  // ... nor in front of it
+    }
+  }
+  // ---- stream_copy: any length and alignment
+  for (int trial = 0; trial < 400; ++trial) {
+    const size_t bytes = 8 * (rnd() % 700);
+    const size_t shift = 8 * (rnd() % 8);
+    std::vector<char> src(bytes + 8), buf(bytes + 128 + 64, (char)0xEE);
+    for (auto& c : src) c = (char)(rnd() & 0xff);
+    char* base = buf.data();
+    base += (64 - (reinterpret_cast<uintptr_t>(base) & 63)) & 63;
+    char* dst = base + 64 + shift;
+    stream_copy(dst, src.data(), bytes);
+    _mm_sfence();
+    CHECK(memcmp(dst, src.data(), bytes) == 0);
+    CHECK((unsigned char)dst[bytes] == 0xEE && (unsigned char)dst[-1] == 0xEE);
+  }
+  // ---- transfer_spans: the spans tile the slab on the device side, land inside the destination, and merge when both sides are contiguous
+  for (int trial = 0; trial < 2000; ++trial) {
+    const int op = (int)(rnd() % INFLX_OP_COUNT);
+    const int layout = (int)(rnd() % 2);
+    const size_t P = 1 + rnd() % 5, N1 = 1 + rnd() % 70, rc = 1 + rnd() % 40;
+    HostDest d;
+    d.dst_rows = rc + rnd() % 30;
+    d.dst_row0 = rnd() % (d.dst_rows - rc + 1);
+    const std::vector<Span> spans = transfer_spans(op, P, N1, rc, layout, d);
+    size_t src_end = 0, total = 0;
+    for (const Span& sp : spans) {
+      CHECK(sp.src == src_end);  // device side: back to back, in order
+      src_end = sp.src + sp.bytes;
+      total += sp.bytes;
+      CHECK(sp.dst + sp.bytes <= P * d.dst_rows * N1 * kOpBytes[op]);
+    }
+    CHECK(total == P * rc * N1 * kOpBytes[op]);
+    if (d.dst_rows == rc) CHECK(spans.size() == 1);  // the destination IS the slab: one copy
+    for (size_t k = 1; k < spans.size(); ++k) CHECK(spans[k].dst >= spans[k - 1].dst + spans[k - 1].bytes);  // disjoint, ascending
+  }
+  // ---- the partition of a multi-device sweep covers the index space exactly once
+  for (int trial = 0; trial < 3000; ++trial) {
+    const size_t P = 1 + rnd() % 40, N0 = 1 + rnd() % 500, world = 1 + rnd() % 9;
+    size_t p_seen = 0, r_seen = 0;
+    int axis = -1;
+    for (size_t k = 0; k < world; ++k) {
+      const ShardPlan s = shard_plan(P, N0, world, k);
+      if (axis < 0) axis = s.axis;
+      CHECK(s.axis == axis && axis == (P >= world ? 0 : 1));
+      if (axis == 0) {
+        CHECK(s.p_begin == p_seen && s.row_begin == 0 && s.row_count == N0);
+        p_seen += s.p_count;
+      } else {
+        CHECK(s.row_begin == r_seen && s.p_begin == 0 && s.p_count == P);
+        r_seen += s.row_count;
+      }
+    }
+    CHECK(axis == 0 ? p_seen == P : r_seen == N0);
+    size_t plan[5];
+    CHECK(inflx_shard_plan(P, N0, (int)world, (int)(world - 1), plan) == INFLX_OK);
+    CHECK(inflx_shard_plan(P, N0, (int)world, (int)world, plan) != INFLX_OK);  // rank out of range
+  }
+  // ---- page helpers on a fresh mapping: contents preserved, partial pages at both ends left alone
+  {
+    const size_t bytes = (size_t(3) << 20) + 1234;
+    char* p = (char*)mmap(nullptr, bytes + 8192, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    CHECK(p != MAP_FAILED);
+    for (size_t k = 0; k < bytes; k += 997) p[100 + k] = (char)(k & 0x7f);
+    prefault_range(p + 100, bytes);
+    touch_range(p + 100, bytes);
+    advise_huge_pages(p + 100, bytes);
+    for (size_t k = 0; k < bytes; k += 997) CHECK(p[100 + k] == (char)(k & 0x7f));
+    prefault_range(p + 5, 10);  // shorter than a page: nothing to do, nothing touched
+    munmap(p, bytes + 8192);
+  }
+  // ---- parallel_blocks covers [0, n) once, also when n is smaller than the thread count
+  for (size_t n : {size_t(0), size_t(1), size_t(3), size_t(1000), size_t(100000)}) {
+    std::vector<std::atomic<int>> hits(n);
+    for (auto& h : hits) h = 0;
+    parallel_blocks(n, 4096, [&](size_t a, size_t b) {
+      for (size_t k = a; k < b; ++k) hits[k]++;
+    });
+    for (size_t k = 0; k < n; ++k) CHECK(hits[k] == 1);
+  }
+  // ---- the reporter starts and stops cleanly whether or not it ever prints
+  {
+    Progress pr;
+    pr.total = 100;
+    Reporter silent(&pr, 1e6, true);  // below INFLX_PROGRESS_MIN_MB: no thread
+    CHECK(!silent.active());
+    Progress big;
+    big.total = uint64_t(8) << 30;
+    {
+      Reporter r(&big, 1e9, true);
+      CHECK(r.active());
+      big.done += uint64_t(1) << 30;
+    }
+    Reporter off(&big, 1e9, false);
+    CHECK(!off.active());
+  }
+  // ---- argument validation of the entry points that need no device
+  CHECK(inflx_open(nullptr, 0, nullptr) == INFLX_ERR_ARG);
+  CHECK(inflx_sweep_host_multi(nullptr, 0, nullptr, 1, 1, nullptr, nullptr, 1, 1, 0, 0, 0) == INFLX_ERR_ARG);
+  CHECK(inflx_multi_device_count(nullptr) == 0 && inflx_multi_handle(nullptr, 0) == nullptr);
+  inflx_close(nullptr);
+  inflx_close_multi(nullptr);
+  printf("host_units: all checks passed\n");
+  return 0;
+}

@@ -71,3 +71,26 @@ def test_code_object_exports_the_model_abi():
     for op in ("complete", "consistency", "rapidturn", "epsilon_v", "raw"):
         for kind in ("tile", "rows", "traj"):
             assert f"inflx_sweep_{kind}_{op}" in exported
+
+
+def test_host_helpers_under_address_and_ub_sanitizers(tmp_path):
+    """tests/host_units.cpp: the hand-written memory code of the host library (streaming-store fill, transfer spans, page helpers,
+    the multi-device partition, the progress reporter) compiled TOGETHER WITH the library source under ASan + UBSan and run on the
+    CPU -- sanitizers are a CPU-only tool on this pool, and these helpers never call into HIP."""
+    import shutil
+    import subprocess
+
+    import pytest
+
+    gxx = shutil.which("g++")
+    rocm = "/opt/rocm"
+    if gxx is None or not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime.h")):
+        pytest.skip("g++ or the HIP headers are not available")
+    exe = str(tmp_path / "host_units")
+    cmd = [gxx, "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer", "-D__HIP_PLATFORM_AMD__",
+           f"-I{rocm}/include", f"-I{os.path.join(ROOT, 'include')}", f"-I{os.path.join(ROOT, 'inflatox_amd', 'csrc')}",
+           os.path.join(ROOT, "tests", "host_units.cpp"), "-o", exe, f"-L{rocm}/lib", "-lamdhip64", "-lpthread", f"-Wl,-rpath,{rocm}/lib"]  # fmt: skip
+    built = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert built.returncode == 0, built.stderr[-3000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert run.returncode == 0 and "all checks passed" in run.stdout, (run.stdout + run.stderr)[-3000:]
