@@ -15,7 +15,9 @@ _DP = C.POINTER(C.c_double)
 
 class HostTwin:
     def __init__(self, header_text: str, contract: str = "off"):
-        tag = hashlib.sha1((header_text + contract).encode()).hexdigest()[:16]
+        # INFLX_TEST_SANITIZE=1 (manual runs under LD_PRELOAD=libasan.so): the generated stage code and csrc/inflx_ops.h under ASan + UBSan
+        sanitize = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("INFLX_TEST_SANITIZE") else []
+        tag = hashlib.sha1((header_text + contract + " ".join(sanitize)).encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "inflx_host_twin")
         os.makedirs(d, exist_ok=True)
         hdr = os.path.join(d, f"{tag}.h")
@@ -24,7 +26,7 @@ class HostTwin:
             with open(hdr, "w") as fh:
                 fh.write(header_text)
             cmd = [
-                "g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-ffp-contract={contract}", "-fno-fast-math", "-Wno-unknown-pragmas",
+                "g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-ffp-contract={contract}", "-fno-fast-math", "-Wno-unknown-pragmas", *sanitize,
                 f"-I{os.path.join(ROOT, 'inflatox_amd', 'csrc')}", f'-DINFLX_MODEL_HEADER="{hdr}"',
                 os.path.join(HERE, "host_twin.cpp"), "-o", so + ".tmp",
             ]  # fmt: skip

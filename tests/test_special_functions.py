@@ -32,9 +32,12 @@ def sf():
     h = hashlib.sha1()
     for f in (src, os.path.join(csrc, "inflx_sf.h"), os.path.join(csrc, "inflx_sf_tables.h")):
         h.update(open(f, "rb").read())
-    so = os.path.join(tempfile.gettempdir(), f"inflx_sf_host_{h.hexdigest()[:12]}.so")
+    # INFLX_TEST_SANITIZE=1 (manual runs: LD_PRELOAD=$(g++ -print-file-name=libasan.so) ASAN_OPTIONS=detect_leaks=0 python -m pytest ...):
+    # the same functions under ASan + UBSan -- table indices, shifts and integer conversions of csrc/inflx_sf.h
+    sanitize = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("INFLX_TEST_SANITIZE") else []
+    so = os.path.join(tempfile.gettempdir(), f"inflx_sf_host_{h.hexdigest()[:12]}{'_san' if sanitize else ''}.so")
     if not os.path.exists(so):
-        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mfma", "-ffp-contract=off", f"-I{csrc}", src, "-o", so + ".tmp"], check=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-mfma", "-ffp-contract=off", *sanitize, f"-I{csrc}", src, "-o", so + ".tmp"], check=True)
         os.replace(so + ".tmp", so)
     return C.CDLL(so)
 
