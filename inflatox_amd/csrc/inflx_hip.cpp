@@ -597,7 +597,7 @@ int launch_rows_fallback(inflx_model* m, int op, InflxSweepArgs a, size_t P, siz
 // so that in a sequence of launches the tables of launch n+1 are evaluated while the tile kernel of launch n runs.
 // grid.y is limited to 65535 tiles: a taller slab takes several launches, each with tables of its own; parameter rows
 // are batched so that one set of tables stays below 1 GiB.
-constexpr size_t kSmallLaunchWorkgroups = 256;  // a tile launch with fewer workgroups than the chip has CUs gets lower tiles
+constexpr size_t kLaunchWorkgroups = 1024;  // workgroups a tile launch is cut into when full-height tiles would give fewer (256 CUs x 3-4 resident)
 
 int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
                  double* d_stats) {
@@ -643,13 +643,13 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
         HIP_TRY(hipEventRecord(m->stage_ready[b], tables));
         HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
       }
-      // Tile height of this launch.  The kernels walk a tile's rows one after the other: a grid with fewer full-height tiles
-      // than the chip has CUs (1000 x 1000: 128, 256 x 256: 8) would leave most of it idle for the time of 32 rows, so such a
-      // launch is cut into lower tiles -- about two workgroups per CU, one round whatever the occupancy -- and every
-      // wavefront has a quarter (an eighth ...) of the rows to walk.  Larger grids keep the full height and its amortisation
-      // of the per-tile prologue.
-      size_t th = m->info.tile_rows;
-      if (gx * ((slab + th - 1) / th) * pb < kSmallLaunchWorkgroups) th = std::min(th, std::max<size_t>(2, (gx * slab * pb + 2 * kSmallLaunchWorkgroups - 1) / (2 * kSmallLaunchWorkgroups)));
+      // Tile height of this launch.  The kernels walk a tile's rows one after the other, and a CU holds three or four workgroups:
+      // a launch of fewer than ~1000 full-height tiles leaves CUs idle or half occupied for the time of 32 rows (256 x 256: 8 tiles,
+      // 1000 x 1000: 128, 2048 x 2048: 512 -- two per CU, where D5 then takes 0.167 ms instead of 0.130).  The height is therefore
+      // what gives the launch about 1024 workgroups, between 1 row and the full height; large launches keep the full height and
+      // its amortisation of the per-tile prologue (scripts/tile_rows_probe.py, profiles/r04_experiments.txt section 17).
+      size_t th = std::min<size_t>(m->info.tile_rows, std::max<size_t>(1, gx * slab * pb / kLaunchWorkgroups));
+      if (const char* e = getenv("INFLX_EXPERIMENT_TILE_ROWS")) th = std::min<size_t>(m->info.tile_rows, (size_t)std::max(1, atoi(e)));  // (experiments: scripts/tile_rows_probe.py)
       a.tile_rows = (uint32_t)th;
       const size_t gy = (slab + th - 1) / th;
       HIP_TRY(probe_begin(m, s));
