@@ -646,9 +646,12 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
       // Tile height of this launch.  The kernels walk a tile's rows one after the other, and a CU holds three or four workgroups:
       // a launch of fewer than ~1000 full-height tiles leaves CUs idle or half occupied for the time of 32 rows (256 x 256: 8 tiles,
       // 1000 x 1000: 128, 2048 x 2048: 512 -- two per CU, where D5 then takes 0.167 ms instead of 0.130).  The height is therefore
-      // what gives the launch about 1024 workgroups, between 1 row and the full height; large launches keep the full height and
-      // its amortisation of the per-tile prologue (scripts/tile_rows_probe.py, profiles/r04_experiments.txt section 17).
-      size_t th = std::min<size_t>(m->info.tile_rows, std::max<size_t>(1, gx * slab * pb / kLaunchWorkgroups));
+      // what gives the launch about 1024 workgroups, between 1 row and half the full height; half-height tiles then stay until they
+      // number 4096 (a launch of two to four rounds of full-height workgroups ends with a ragged last round: 4096 x 4096 is 2.7), and
+      // large launches have the full height and its amortisation of the per-tile prologue (scripts/tile_rows_probe.py,
+      // profiles/r04_experiments.txt section 17).
+      const size_t segments = gx * slab * pb, full = m->info.tile_rows;
+      size_t th = std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
       if (const char* e = getenv("INFLX_EXPERIMENT_TILE_ROWS")) th = std::min<size_t>(m->info.tile_rows, (size_t)std::max(1, atoi(e)));  // (experiments: scripts/tile_rows_probe.py)
       a.tile_rows = (uint32_t)th;
       const size_t gy = (slab + th - 1) / th;
