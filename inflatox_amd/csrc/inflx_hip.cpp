@@ -652,7 +652,14 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
       // profiles/r04_experiments.txt section 17).
       const size_t segments = gx * slab * pb, full = m->info.tile_rows;
       size_t th = std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
-      if (const char* e = getenv("INFLX_EXPERIMENT_TILE_ROWS")) th = std::min<size_t>(m->info.tile_rows, (size_t)std::max(1, atoi(e)));  // (experiments: scripts/tile_rows_probe.py)
+      // (experiments, scripts/tile_rows_probe.py: a height forced through the environment -- looked at per launch only if the variable
+      // existed when the first sweep ran, so that ordinary processes never read the environment while other threads may be writing it)
+      static const bool forced = getenv("INFLX_EXPERIMENT_TILE_ROWS") != nullptr;
+      if (forced) {
+        const char* e = getenv("INFLX_EXPERIMENT_TILE_ROWS");
+        const int rows = e ? atoi(e) : 0;
+        if (rows > 0) th = std::min<size_t>(full, (size_t)rows);
+      }
       a.tile_rows = (uint32_t)th;
       const size_t gy = (slab + th - 1) / th;
       HIP_TRY(probe_begin(m, s));

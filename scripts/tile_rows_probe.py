@@ -8,6 +8,8 @@ import sys
 import numpy as np
 import torch
 
+os.environ["INFLX_EXPERIMENT_TILE_ROWS"] = "0"  # arms the knob (the library looks for it once, at its first tile launch); 0 = the library's own choice
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import workloads  # noqa: E402
@@ -29,11 +31,11 @@ for name in argv or ["doc", "egno", "d5"]:
         for _ in range(4):
             for h in HEIGHTS + ("rule",):
                 if h == "rule":  # the height launch_tiles chooses by itself
-                    os.environ.pop("INFLX_EXPERIMENT_TILE_ROWS", None)
+                    os.environ["INFLX_EXPERIMENT_TILE_ROWS"] = "0"
                 else:
                     os.environ["INFLX_EXPERIMENT_TILE_ROWS"] = str(h)
                 ms = lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=max(5, int(40 / P)) * (4 if small else 1))
                 best[h] = min(best[h], ms)
-        os.environ.pop("INFLX_EXPERIMENT_TILE_ROWS", None)
+        os.environ["INFLX_EXPERIMENT_TILE_ROWS"] = "0"
         print(f"{name:6s} {n}^2 x {P}: " + "   ".join(f"{h:2d} rows {best[h]:7.4f} ms" for h in HEIGHTS) + f"   | launch_tiles' own choice {best['rule']:7.4f} ms", flush=True)
         del buf
