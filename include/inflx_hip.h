@@ -164,7 +164,9 @@ int inflx_sweep_device(inflx_model* model, int op, const double* p, size_t P, si
 /*
  * Which kernels a sweep of this shape takes (introspection for tests and profiles; no launch):
  *   plan[0] inflx_path; for INFLX_PATH_ROW_STREAM also plan[1] = parameter rows per row-table batch,
- *   plan[2] = number of batches the call is cut into, plan[3] = replicas of a row's table entry.
+ *   plan[2] = number of batches the call is cut into, plan[3] = replicas of a row's table entry;
+ *   for INFLX_PATH_TILE plan[1] = parameter rows per launch, plan[2] = number of launches, plan[3] = grid rows per workgroup
+ *   tile of the first launch (the full height for large launches, lower for launches of fewer than ~4096 tiles).
  */
 typedef enum inflx_path {
   INFLX_PATH_TILE = 0,       /* inflx_sweep_tile_*: some model value depends on x[1]                    */

@@ -383,10 +383,16 @@ class InflatoxDevLib:
         return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 
     def sweep_plan(self, op, P, N1, row_count, layout=LAYOUT_AOS) -> dict:
-        """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows"|"col_stream", "batch_rows", "batches", "replicas"}``."""
+        """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows"|"col_stream", "batch_rows", "batches", "replicas"}``;
+        for the tile path ``batch_rows`` = parameter rows per launch, ``batches`` = launches, and ``tile_rows`` = grid rows per workgroup
+        tile of the first launch."""
         plan = (C.c_uint32 * 4)()
         _check(self._lib.inflx_sweep_plan(self._h, op, P, N1, row_count, layout, plan))
-        return {"path": ("tile", "row_stream", "rows", "col_stream")[plan[0]], "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
+        path = ("tile", "row_stream", "rows", "col_stream")[plan[0]]
+        out = {"path": path, "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
+        if path == "tile":
+            out["tile_rows"] = out.pop("replicas")
+        return out
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))

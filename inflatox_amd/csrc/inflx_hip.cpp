@@ -599,6 +599,17 @@ int launch_rows_fallback(inflx_model* m, int op, InflxSweepArgs a, size_t P, siz
 // are batched so that one set of tables stays below 1 GiB.
 constexpr size_t kLaunchWorkgroups = 1024;  // workgroups a tile launch is cut into when full-height tiles would give fewer (256 CUs x 3-4 resident)
 
+// Tile height of a launch of `segments` = column tiles x grid rows x parameter rows.  The kernels walk a tile's rows one after
+// the other, and a CU holds three or four workgroups: a launch of fewer than ~1000 full-height tiles leaves CUs idle or half
+// occupied for the time of 32 rows (256 x 256: 8 tiles, 1000 x 1000: 128, 2048 x 2048: 512 -- two per CU, where D5 then takes
+// 0.167 ms instead of 0.130).  The height is therefore what gives the launch about 1024 workgroups, between 1 row and half the
+// full height; half-height tiles then stay until they number 4096 (a launch of two to four rounds of full-height workgroups ends
+// with a ragged last round: 4096 x 4096 is 2.7), and large launches have the full height and its amortisation of the per-tile
+// prologue (scripts/tile_rows_probe.py, profiles/r04_experiments.txt section 17).
+size_t tile_height(size_t full, size_t segments) {
+  return std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
+}
+
 int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
                  double* d_stats) {
   void* params[] = {&a};
@@ -643,15 +654,8 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
         HIP_TRY(hipEventRecord(m->stage_ready[b], tables));
         HIP_TRY(hipStreamWaitEvent(s, m->stage_ready[b], 0));
       }
-      // Tile height of this launch.  The kernels walk a tile's rows one after the other, and a CU holds three or four workgroups:
-      // a launch of fewer than ~1000 full-height tiles leaves CUs idle or half occupied for the time of 32 rows (256 x 256: 8 tiles,
-      // 1000 x 1000: 128, 2048 x 2048: 512 -- two per CU, where D5 then takes 0.167 ms instead of 0.130).  The height is therefore
-      // what gives the launch about 1024 workgroups, between 1 row and half the full height; half-height tiles then stay until they
-      // number 4096 (a launch of two to four rounds of full-height workgroups ends with a ragged last round: 4096 x 4096 is 2.7), and
-      // large launches have the full height and its amortisation of the per-tile prologue (scripts/tile_rows_probe.py,
-      // profiles/r04_experiments.txt section 17).
-      const size_t segments = gx * slab * pb, full = m->info.tile_rows;
-      size_t th = std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
+      const size_t full = m->info.tile_rows;
+      size_t th = tile_height(full, gx * slab * pb);
       // (experiments, scripts/tile_rows_probe.py: a height forced through the environment -- looked at per launch only if the variable
       // existed when the first sweep ran, so that ordinary processes never read the environment while other threads may be writing it)
       static const bool forced = getenv("INFLX_EXPERIMENT_TILE_ROWS") != nullptr;
@@ -1007,6 +1011,11 @@ int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t r
     plan[0] = INFLX_PATH_ROWS;
   } else {
     plan[0] = INFLX_PATH_TILE;
+    const TilePlan t = tile_plan(m, P, N1, row_count);
+    const size_t gx = (N1 + m->info.tile_cols - 1) / m->info.tile_cols, slab = std::min(t.rows_per_launch, row_count);
+    plan[1] = (uint32_t)t.pbatch;
+    plan[2] = (uint32_t)(((P + t.pbatch - 1) / t.pbatch) * ((row_count + t.rows_per_launch - 1) / t.rows_per_launch));
+    plan[3] = (uint32_t)tile_height(m->info.tile_rows, gx * slab * t.pbatch);
   }
   return INFLX_OK;
 }

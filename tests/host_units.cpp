@@ -115,6 +115,21 @@ int main() {
     });
     for (size_t k = 0; k < n; ++k) CHECK(hits[k] == 1);
   }
+  // ---- tile height of a launch: 1 ... full, never more workgroups than segments, ~1024 workgroups for small launches, the full height for large ones
+  {
+    const size_t full = 32;
+    CHECK(tile_height(full, 1) == 1 && tile_height(full, 256) == 1);              // 256 x 256: one row per workgroup
+    CHECK(tile_height(full, 4 * 1000) == 3);                                      // 1000 x 1000 (4 column tiles)
+    CHECK(tile_height(full, 8 * 2048) == 16 && tile_height(full, 16 * 4096) == 16);  // 2048^2, 4096^2: half height
+    CHECK(tile_height(full, 4 * 16 * 4096) == 32 && tile_height(full, size_t(1) << 40) == 32);
+    size_t last = 1;
+    for (size_t seg = 1; seg < (size_t(1) << 22); seg += 1 + seg / 37) {
+      const size_t th = tile_height(full, seg);
+      CHECK(th >= 1 && th <= full && th >= last);  // monotone in the size of the launch
+      last = th;
+      if (th < full / 2) CHECK(seg / th >= 1024 || th == 1);  // lower tiles only while they are needed to reach ~1024 workgroups
+    }
+  }
   // ---- the reporter starts and stops cleanly whether or not it ever prints
   {
     Progress pr;

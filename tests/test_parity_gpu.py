@@ -1261,3 +1261,17 @@ def test_soak_of_bursts_and_geometries(gpu_lib):
     last = proc.stdout.strip().splitlines()[-1]
     assert last.startswith("soak finished") and "all bit-equal" in last, last
     assert int(last.split()[2]) >= 100, last  # cases
+
+
+def test_tile_launch_plan_of_typical_grids(gpu_lib):
+    """inflx_sweep_plan for the tile path: small grids are cut into lower workgroup tiles (the kernels walk a tile's rows one after the
+    other: 256 x 256 would be eight 32-row workgroups on 256 CUs), large launches keep the full height; the results do not depend on it
+    (test_geometry_fuzz_sweeps_equal_point_evaluation, scripts/soak.py cover heights 1 ... 32)."""
+    spec, art, lib = devlib("doc", gpu_lib)
+    full = 32
+    for n, P, rows in ((256, 1, 1), (1000, 1, 3), (2048, 1, 16), (4096, 1, 16), (4096, 32, full), (256, 64, 16)):
+        plan = lib.sweep_plan(gpu_lib.OP_COMPLETE, P, n, n)
+        assert plan["path"] == "tile" and plan["batches"] == 1 and plan["batch_rows"] == P and plan["tile_rows"] == rows, (n, P, plan)
+    # more than 65535 full-height tiles of rows: several launches
+    tall = lib.sweep_plan(gpu_lib.OP_COMPLETE, 1, 2, 2100001)
+    assert tall["batches"] == 2 and tall["tile_rows"] == full
