@@ -72,9 +72,15 @@ class InflationCondition:
     def calc_H_array(self, args, x0_start, x0_stop, x1_start, x1_stop, N=None) -> np.ndarray:
         """Projected Hesse matrix on the grid, shape (2, 2, N0, N1) as the reference documents
         (consistency_conditions.py:119-156; its implementation passes the wrong arguments to the native
-        helper and cannot run, so the documented contract is what is implemented).  v01 is filled from v10."""
+        helper and cannot run, so the documented contract is what is implemented).  v01 is v10 (the sweep kernels carry v10
+        only): the result is a read-only view in which ``H[0, 1]`` and ``H[1, 0]`` are the same memory."""
         raw = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N)
-        return np.stack([np.stack([raw[1], raw[2]]), np.stack([raw[2], raw[3]])])
+        # H[a, b] is plane 1 + a + b of the five raw planes (V, v00, v10, v11, |dV|^2): a strided view, not a copy -- at the default
+        # 8000 x 8000 grid the four planes are 2 GB.  H[0, 1] and H[1, 0] are the same memory (the matrix is symmetric), so the view
+        # is read-only; ``.copy()`` gives an independent array.
+        plane = raw.strides[0]
+        view = np.lib.stride_tricks.as_strided(raw[1:], shape=(2, 2) + raw.shape[1:], strides=(plane, plane) + raw.strides[1:], writeable=False)
+        return view
 
     def validate_basis_on_domain(self, args, start, stop, N=100, accuracy: float = 1e-3) -> None:
         """Checks that the basis {v, w1} is orthonormal (to ``accuracy``) on sample points of the domain

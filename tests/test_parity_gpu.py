@@ -384,6 +384,8 @@ def test_array_helpers(gpu_lib):
     compare(V, raw[..., 0], 1e-10, "calc_V_array")
     H = al.calc_H_array(spec.args, 0.5, 2.5, 0.0, 3.0, [n0, n1])
     assert H.shape == (2, 2, n0, n1)
+    assert not H.flags.writeable and np.shares_memory(H[0, 1], H[1, 0])  # a view of the raw planes, not a 2 GB copy at the default size
+    assert H.copy().flags.writeable and np.array_equal(np.ascontiguousarray(H), H, equal_nan=True)
     for (a, b), k in (((0, 0), 1), ((1, 0), 2), ((0, 1), 2), ((1, 1), 3)):
         compare(H[a, b], raw[..., k], 1e-9, f"calc_H_array[{a}{b}]")
 
