@@ -150,6 +150,16 @@ int inflx_sweep_host(inflx_model* model, int op, const double* p, size_t P, size
                      const double* start_stop, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout);
 
 /*
+ * As inflx_sweep_host with the planes layout, but only planes [first_plane, first_plane + n_planes) of every parameter row cross
+ * PCIe: `out` holds P*n_planes*row_count*N1 doubles, (P, n_planes, row_count, N1).  The device evaluates all K values of the
+ * operation in one pass; a caller that wants one of them (calc_V_array: plane 0 of the five raw values, reference
+ * consistency_conditions.py:67-101; calc_H_array: planes 1-3, :119-156) does not pay the copy of the others.
+ */
+int inflx_sweep_host_planes(inflx_model* model, int op, const double* p, size_t P, size_t n_p, double* out,
+                            const double* start_stop, size_t N0, size_t N1, size_t row_begin, size_t row_count,
+                            size_t first_plane, size_t n_planes);
+
+/*
  * Generalised sweep, device-resident result: `d_out` is device memory of at least
  * P*row_count*N1*K*8 bytes on the model's device (`d_out_bytes` is checked); the kernel is
  * enqueued on `stream` (a hipStream_t; NULL = the model's own stream) and the call returns without

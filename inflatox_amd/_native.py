@@ -44,6 +44,7 @@ SIGNATURES = {
     "inflx_flag_quantum_dif": (C.c_int, [C.c_void_p, _DP, _SIZE, C.POINTER(C.c_uint8), _DP, _SIZE, _SIZE, C.c_int, C.c_double]),
     "inflx_sweep_on_trajectory": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _DP, _SIZE, _DP, C.c_int, _SIZE]),
     "inflx_sweep_host": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int]),
+    "inflx_sweep_host_planes": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, _DP, _DP, _SIZE, _SIZE, _SIZE, _SIZE, _SIZE, _SIZE]),
     "inflx_sweep_device": (
         C.c_int,
         [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p],
@@ -337,6 +338,20 @@ class InflatoxDevLib:
 
         out = result_array(shape)  # recycled page-resident memory where a dropped result of this size is at hand
         _check(self._lib.inflx_sweep_host(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, layout))
+        return out[0] if single else out
+
+    def sweep_host_planes(self, op, p, start_stop, N0, N1, first_plane, n_planes, row_begin=0, row_count=None) -> np.ndarray:
+        """Planes ``[first_plane, first_plane + n_planes)`` of the planes-layout result of ``op``: (P, n_planes, rows, N1), or
+        (n_planes, rows, N1) for a single parameter row.  Only those planes are copied to the host."""
+        p = _f64(p, "p")
+        single = p.ndim == 1
+        p2 = p.reshape(1, -1) if single else p
+        ss = _f64(start_stop, "start_stop").reshape(-1)
+        row_count = N0 - row_begin if row_count is None else row_count
+        from ._result_pool import result_array
+
+        out = result_array((p2.shape[0], n_planes, row_count, N1))
+        _check(self._lib.inflx_sweep_host_planes(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, first_plane, n_planes))
         return out[0] if single else out
 
     def sweep_device(self, op, p, d_out_ptr: int, d_out_bytes: int, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0):

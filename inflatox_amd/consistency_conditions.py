@@ -59,28 +59,28 @@ class InflationCondition:
 
 
     # -- array helpers (reference :67-101,119-156); off the sweep path, served by the raw-values sweep ----
-    def _raw_planes(self, args, x0_start, x0_stop, x1_start, x1_stop, N):
+    def _raw_planes(self, args, x0_start, x0_stop, x1_start, x1_stop, N, first, count):
+        """Planes [first, first + count) of the raw values (V, v00, v10, v11, |dV|^2) on the grid; only those cross PCIe."""
         n0, n1 = (int(v) for v in (N if N is not None else (8000, 8000)))
         ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
-        return self.dylib.sweep_host(_native.OP_RAW, args, ss, n0, n1, layout=_native.LAYOUT_SOA)
+        return self.dylib.sweep_host_planes(_native.OP_RAW, args, ss, n0, n1, first, count)
 
     def calc_V_array(self, args, start, stop, N=None) -> np.ndarray:
         """Potential on the grid ``start[i] + k*(stop[i]-start[i])/N[i]`` (end point excluded), shape ``N``
         (reference consistency_conditions.py:67-101, hesse_bindings.rs:68-85)."""
-        return self._raw_planes(args, start[0], stop[0], start[1], stop[1], N)[0]
+        return self._raw_planes(args, start[0], stop[0], start[1], stop[1], N, 0, 1)[0]
 
     def calc_H_array(self, args, x0_start, x0_stop, x1_start, x1_stop, N=None) -> np.ndarray:
         """Projected Hesse matrix on the grid, shape (2, 2, N0, N1) as the reference documents
         (consistency_conditions.py:119-156; its implementation passes the wrong arguments to the native
         helper and cannot run, so the documented contract is what is implemented).  v01 is v10 (the sweep kernels carry v10
         only): the result is a read-only view in which ``H[0, 1]`` and ``H[1, 0]`` are the same memory."""
-        raw = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N)
-        # H[a, b] is plane 1 + a + b of the five raw planes (V, v00, v10, v11, |dV|^2): a strided view, not a copy -- at the default
-        # 8000 x 8000 grid the four planes are 2 GB.  H[0, 1] and H[1, 0] are the same memory (the matrix is symmetric), so the view
-        # is read-only; ``.copy()`` gives an independent array.
-        plane = raw.strides[0]
-        view = np.lib.stride_tricks.as_strided(raw[1:], shape=(2, 2) + raw.shape[1:], strides=(plane, plane) + raw.strides[1:], writeable=False)
-        return view
+        hess = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N, 1, 3)  # v00, v10, v11
+        # H[a, b] is plane a + b of those three: a strided view, not a copy -- at the default 8000 x 8000 grid four planes would be
+        # 2 GB.  H[0, 1] and H[1, 0] are the same memory (the matrix is symmetric), so the view is read-only; ``.copy()`` gives an
+        # independent array.
+        plane = hess.strides[0]
+        return np.lib.stride_tricks.as_strided(hess, shape=(2, 2) + hess.shape[1:], strides=(plane, plane) + hess.strides[1:], writeable=False)
 
     def validate_basis_on_domain(self, args, start, stop, N=100, accuracy: float = 1e-3) -> None:
         """Checks that the basis {v, w1} is orthonormal (to ``accuracy``) on sample points of the domain

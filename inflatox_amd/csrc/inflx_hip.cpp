@@ -1269,6 +1269,11 @@ namespace {
 struct HostDest {
   size_t dst_rows = 0;
   size_t dst_row0 = 0;
+  // plane subset of a planes (SoA) result: only planes [plane0, plane0 + planes) of every parameter row are copied to the host, into a
+  // destination of `planes` planes per parameter row (planes = 0: all of them).  The device evaluates every plane -- the model's values
+  // come out of one evaluation -- but calc_V_array wants one of five and the copy is what a host-result call pays for.
+  size_t plane0 = 0;
+  size_t planes = 0;
 };
 
 // Bytes that have arrived in the caller's array, for the progress lines of long host-result calls (shared by the
@@ -1291,8 +1296,15 @@ std::vector<Span> transfer_spans(int op, size_t P, size_t N1, size_t row_count, 
   const size_t blocks = planes ? P * K : P;                              // contiguous blocks of rows on both sides
   const size_t row_bytes = planes ? N1 * sizeof(double) : N1 * kOpBytes[op];
   std::vector<Span> spans;
+  const bool subset = planes && d.planes != 0;
   for (size_t b = 0; b < blocks; ++b) {
-    const Span sp{b * row_count * row_bytes, (b * d.dst_rows + d.dst_row0) * row_bytes, row_count * row_bytes};
+    size_t dst_block = b;
+    if (subset) {
+      const size_t pr = b / K, k = b % K;
+      if (k < d.plane0 || k >= d.plane0 + d.planes) continue;
+      dst_block = pr * d.planes + (k - d.plane0);
+    }
+    const Span sp{b * row_count * row_bytes, (dst_block * d.dst_rows + d.dst_row0) * row_bytes, row_count * row_bytes};
     if (!spans.empty() && spans.back().src + spans.back().bytes == sp.src && spans.back().dst + spans.back().bytes == sp.dst)
       spans.back().bytes += sp.bytes;
     else
@@ -1476,12 +1488,15 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   const size_t K = kOpWidth[op];
   const size_t row_bytes = N1 * kOpBytes[op];
   const size_t total = P * row_count * row_bytes;
-  if (op != INFLX_OP_QDIF && host_fill_enabled() && total >= host_fill_min_bytes()) {
+  const bool subset = dest.planes != 0;
+  if (subset && (layout != INFLX_SOA || K == 1 || dest.plane0 + dest.planes > K))
+    return fail(INFLX_ERR_ARG, "a plane subset [%zu, %zu) needs the planes layout of an operation with at least that many values (this one has %zu)", dest.plane0, dest.plane0 + dest.planes, K);
+  if (!subset && op != INFLX_OP_QDIF && host_fill_enabled() && total >= host_fill_min_bytes()) {
     // a result that is constant along a grid axis is written by host threads from the one evaluated line
     if ((m->info.out_mask & 2u) == 0 && N1 > 1) return sweep_host_broadcast(m, op, 1, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
     if ((m->info.out_mask & 3u) == 2u && row_count > 1) return sweep_host_broadcast(m, op, 0, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
   }
-  bool whole = total <= whole_result_limit();
+  bool whole = total <= whole_result_limit() || subset;  // (a plane subset is copied out of the whole result: no chunk pipeline for it)
   if (whole && total > m->d_whole_cap) {
     if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
     m->d_whole = nullptr;
@@ -1492,6 +1507,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       (void)hipGetLastError();  // not enough free HBM for the whole result: the chunk pipeline needs 64 MiB
       m->d_whole = nullptr;
       whole = false;
+      if (subset) return fail(INFLX_ERR_DEVICE, "not enough free device memory for the %zu-byte result a plane subset is copied from", total);
     }
   }
   // the stream of the kernels that read the parameters: decided by the P the launches below really see (the
@@ -1860,6 +1876,16 @@ int inflx_sweep_host(inflx_model* m, int op, const double* p, size_t P, size_t n
                      size_t N1, size_t row_begin, size_t row_count, int layout) {
   if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
   return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, 0.0, HostDest(), nullptr);
+}
+
+int inflx_sweep_host_planes(inflx_model* m, int op, const double* p, size_t P, size_t n_p, double* out, const double* ss, size_t N0,
+                            size_t N1, size_t row_begin, size_t row_count, size_t first_plane, size_t n_planes) {
+  if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
+  if (n_planes == 0) return fail(INFLX_ERR_ARG, "no planes requested");
+  HostDest dest;
+  dest.plane0 = first_plane;
+  dest.planes = n_planes;
+  return sweep_host_impl(m, op, p, P, n_p, out, ss, N0, N1, row_begin, row_count, INFLX_SOA, 0.0, dest, nullptr);
 }
 
 int inflx_flag_quantum_dif(inflx_model* m, const double* p, size_t n_p, uint8_t* out, const double* ss, size_t N0, size_t N1,

@@ -71,6 +71,28 @@ int main() {
     if (d.dst_rows == rc) CHECK(spans.size() == 1);  // the destination IS the slab: one copy
     for (size_t k = 1; k < spans.size(); ++k) CHECK(spans[k].dst >= spans[k - 1].dst + spans[k - 1].bytes);  // disjoint, ascending
   }
+  // ---- plane subsets: exactly the requested planes of every parameter row, packed into a destination of that many planes
+  for (int trial = 0; trial < 500; ++trial) {
+    const int op = (rnd() % 2) ? INFLX_OP_COMPLETE : INFLX_OP_RAW;
+    const size_t K = kOpWidth[op], P = 1 + rnd() % 4, N1 = 1 + rnd() % 50, rc = 1 + rnd() % 30;
+    HostDest d;
+    d.dst_rows = rc;
+    d.planes = 1 + rnd() % K;
+    d.plane0 = rnd() % (K - d.planes + 1);
+    const std::vector<Span> spans = transfer_spans(op, P, N1, rc, INFLX_SOA, d);
+    const size_t plane_bytes = rc * N1 * sizeof(double);
+    size_t total = 0, dst_end = 0;
+    for (const Span& sp : spans) {
+      const size_t k0 = (sp.src / plane_bytes) % K;
+      CHECK(sp.src % plane_bytes == 0 && sp.bytes % plane_bytes == 0);
+      if (d.planes < K) CHECK(k0 >= d.plane0 && k0 + sp.bytes / plane_bytes <= d.plane0 + d.planes);  // (all planes: one span across the parameter rows)
+      CHECK(sp.dst == dst_end);  // the destination is filled back to back
+      dst_end = sp.dst + sp.bytes;
+      total += sp.bytes;
+    }
+    CHECK(total == P * d.planes * plane_bytes);
+    if (d.planes == K) CHECK(spans.size() == 1);
+  }
   // ---- the partition of a multi-device sweep covers the index space exactly once
   for (int trial = 0; trial < 3000; ++trial) {
     const size_t P = 1 + rnd() % 40, N0 = 1 + rnd() % 500, world = 1 + rnd() % 9;

@@ -388,6 +388,21 @@ def test_array_helpers(gpu_lib):
     assert H.copy().flags.writeable and np.array_equal(np.ascontiguousarray(H), H, equal_nan=True)
     for (a, b), k in (((0, 0), 1), ((1, 0), 2), ((0, 1), 2), ((1, 1), 3)):
         compare(H[a, b], raw[..., k], 1e-9, f"calc_H_array[{a}{b}]")
+    # the plane subsets behind the two helpers (inflx_sweep_host_planes: only the requested planes cross PCIe) are the planes of the
+    # full planes-layout sweep bit for bit -- every subset, a parameter batch, a row range
+    lib = al.dylib
+    rows = np.stack([spec.args, spec.args * 1.25])
+    ext = (0.5, 2.5, 0.0, 3.0)
+    full = lib.sweep_host(gpu_lib.OP_RAW, rows, ext, 70, 33, row_begin=5, row_count=41, layout=gpu_lib.LAYOUT_SOA)  # (2, 5, 41, 33)
+    for first, count in ((0, 1), (1, 3), (4, 1), (0, 5), (2, 2)):
+        part = lib.sweep_host_planes(gpu_lib.OP_RAW, rows, ext, 70, 33, first, count, row_begin=5, row_count=41)
+        assert part.shape == (2, count, 41, 33) and np.array_equal(part, full[:, first : first + count], equal_nan=True), (first, count)
+    six = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, 64, 64, layout=gpu_lib.LAYOUT_SOA)
+    assert np.array_equal(lib.sweep_host_planes(gpu_lib.OP_COMPLETE, spec.args, ext, 64, 64, 1, 2), six[1:3], equal_nan=True)  # epsilon_V, epsilon_H alone
+    with pytest.raises(ValueError):
+        lib.sweep_host_planes(gpu_lib.OP_RAW, spec.args, ext, 8, 8, 3, 3)  # planes 3..5 of five
+    with pytest.raises(ValueError):
+        lib.sweep_host_planes(gpu_lib.OP_EPSILON_V, spec.args, ext, 8, 8, 0, 1)  # a single-value operation has no planes
 
 
 @pytest.mark.parametrize("name,loader", [("angular", "npy2"), ("egno", "npy2"), ("d5", "dat")])
