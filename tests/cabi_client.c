@@ -92,6 +92,23 @@ int main(int argc, char** argv) {
     inflx_close_multi(multi);
     free(six2);
   }
+  /* a plane subset of the planes-layout result (what calc_V_array / calc_H_array copy): planes 1-2 of the six = planes 1-2 of the
+   * full planes sweep, and plane k of the planes sweep = value k of the record sweep above */
+  {
+    double* planes = (double*)malloc(n0 * n1 * 6 * sizeof(double));
+    double* two = (double*)malloc(n0 * n1 * 2 * sizeof(double));
+    rc = inflx_sweep_host(model, INFLX_SWEEP_COMPLETE, p, 1, n_p, planes, start_stop, n0, n1, 0, n0, INFLX_SOA);
+    if (rc == INFLX_OK) rc = inflx_sweep_host_planes(model, INFLX_SWEEP_COMPLETE, p, 1, n_p, two, start_stop, n0, n1, 0, n0, 1, 2);
+    int same = rc == INFLX_OK && memcmp(two, planes + n0 * n1, n0 * n1 * 2 * sizeof(double)) == 0;
+    for (size_t i = 0; same && i < n0 * n1; ++i) same = memcmp(&planes[2 * n0 * n1 + i], &six[6 * i + 2], sizeof(double)) == 0;
+    if (!same) {
+      fprintf(stderr, "inflx_sweep_host_planes: status %d (%s) or planes that differ from the full sweep\n", rc, inflx_last_error());
+      return 12;
+    }
+    if (inflx_sweep_host_planes(model, INFLX_SWEEP_COMPLETE, p, 1, n_p, two, start_stop, n0, n1, 0, n0, 5, 2) == INFLX_OK) return 13; /* planes 5-6 of six */
+    free(planes);
+    free(two);
+  }
   FILE* f = fopen(argv[8], "wb");
   if (!f) return 8;
   fwrite(six, sizeof(double), n0 * n1 * 6, f);
