@@ -84,7 +84,9 @@ def recorded(kind: str, key: str, code_id: str):
 
 def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     """Oracle (C restatement of the reference's rayon sweep: five indirect calls per point into the
-    gcc -O3 model object + ops::complete_analysis) on all host cores, bounded sample."""
+    -O3 model object + ops::complete_analysis) on all host cores, bounded sample.  The model object is built by clang when
+    the image has one -- the reference compiles its C with `zig cc`, which is clang (compiler.py:299-310,575-584) --,
+    else by gcc; the compiler is named in `sample`."""
     import numpy as np
 
     import oracle
@@ -93,7 +95,9 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
 
     spec = example_models.get(model_name)
     src, _ = oracle.emit_c_source(workloads.model_for(model_name), **spec.compiler_kwargs)
-    om = oracle.OracleModel(oracle.compile_c_model(src))
+    compilers = oracle.reference_compilers()
+    cc = "clang" if "clang" in compilers else "gcc"
+    om = oracle.OracleModel(oracle.compile_c_model(src, cc=cc))
     cores = host_threads()
     n = 1024
     t0 = time.perf_counter()
@@ -123,7 +127,8 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
         "cores": cores,
         "kind": "port",
         "sample": f"{model_name} {n}x{n} grid over the same extent (per-point cost does not depend on grid size), best of 3 passes, "
-        f"{cores} threads ({os.cpu_count()} logical CPUs on the host), gcc -O3 -march=native model object + C restatement of the Rust sweep",
+        f"{cores} threads ({os.cpu_count()} logical CPUs on the host), {cc} -O3 -march=native model object (reference flag list) + C restatement of the Rust sweep",
+        "model_object_compiler": compilers[cc],
         "configs0_256x256": {"what": "BASELINE configs[0]: the same model on its 256x256 grid, best of 20 passes", "all_threads": at_256(cores), "one_thread": at_256(1)},
     }
 

@@ -8,8 +8,12 @@ Follows (citations relative to /root/reference):
                             grad_norm_squared, eom*, then VERSION/DIM/N_PARAMETERS/MODEL_NAME/USE_GSL)
   * compiler flags          python/inflatox/compiler.py:299-310  (no fast-math!)
 
-The reference shells out to ``zig cc`` (clang); zig is absent here, so the host C compiler
-(``gcc``, or ``clang`` if asked) is used with the same flag list.
+The reference shells out to ``zig cc`` (= clang, compiler.py:299-310,575-584); zig is absent here, so
+the same flag list goes to BOTH C compilers of the image (``reference_compilers()``): ``gcc``, and the
+clang that ships with ROCm -- the closer stand-in for what a user's machine runs.  The two do not compute the same numbers:
+``-std=c17`` puts gcc in ISO mode (= ``-ffp-contract=off``) while clang contracts a*b+c inside an expression into an
+FMA, which moves EGNO's values by 2e-9 (median) and flips NaNs on D5's singular lines.  The tests hold the GPU against
+both (tests/tolerance.py, tests/test_parity_gpu.py ``judge``).
 """
 
 from __future__ import annotations
@@ -23,6 +27,24 @@ import sympy
 from sympy.printing.c import C99CodePrinter
 
 ABI_VERSION = (5, 0, 0)  # python/inflatox/version.py:22
+
+_CLANG_CANDIDATES = ("/opt/rocm/lib/llvm/bin/clang", "/opt/rocm/llvm/bin/clang", "clang")
+
+
+def reference_compilers() -> dict:
+    """``{"gcc": path, "clang": path}`` -- the C compilers of this image that stand in for the reference's ``zig cc``.
+    clang is the one the reference's flag list was written for; a machine without it gets the gcc entry alone."""
+    import shutil
+
+    out = {}
+    if shutil.which("gcc"):
+        out["gcc"] = "gcc"
+    for cand in _CLANG_CANDIDATES:
+        path = cand if os.path.isabs(cand) else shutil.which(cand)
+        if path and os.path.exists(path):
+            out["clang"] = path
+            break
+    return out
 
 REFERENCE_FLAGS = [
     "-O3",
@@ -184,10 +206,12 @@ def emit_c_source(model, cse: bool = False, max_cses: int = 1000, with_eom: bool
 
 
 def compile_c_model(c_source: str, out_dir: str | None = None, cc: str = "gcc", flags=None) -> str:
-    """Compile a generated C file with the reference's flag list; returns the .so path."""
+    """Compile a generated C file with the reference's flag list; returns the .so path.  ``cc``: a compiler path or one
+    of the names of ``reference_compilers()``."""
+    cc = reference_compilers().get(cc, cc)
     out_dir = out_dir or os.path.join(tempfile.gettempdir(), "inflx_oracle_models")
     os.makedirs(out_dir, exist_ok=True)
-    tag = hashlib.sha1((cc + c_source).encode()).hexdigest()[:16]
+    tag = hashlib.sha1((cc + " ".join(flags or REFERENCE_FLAGS) + c_source).encode()).hexdigest()[:16]
     so = os.path.join(out_dir, f"liboracle_model_{tag}.so")
     if not os.path.exists(so):
         src = os.path.join(out_dir, f"oracle_model_{tag}.c")

@@ -24,16 +24,32 @@ def golden(name):
     return dict(np.load(os.path.join(GOLDEN_DIR, f"{name}.npz")))
 
 
+def _compilers():
+    import oracle
+
+    return tuple(oracle.reference_compilers())
+
+
+# The C compilers that stand in for the reference's `zig cc` (oracle/model_c.py): gcc, and the clang of the ROCm image --
+# the closer stand-in, since zig cc IS clang.  gcc -std=c17 does not contract a*b+c, clang does; every reference number
+# exists in both flavours (goldens: key / key + "_clang"; oracle: oracle_model(name, cc)).
+COMPILERS = _compilers()
+
+
+def golden_key(key, cc):
+    return key if cc == "gcc" else f"{key}_{cc}"
+
+
 @functools.lru_cache(maxsize=None)
-def oracle_model(name):
-    """The CPU oracle for an example model: this repo's symbolic stage -> oracle C emitter -> gcc."""
+def oracle_model(name, cc="gcc"):
+    """The CPU oracle for an example model: this repo's symbolic stage -> oracle C emitter -> `cc` (gcc or clang)."""
     import oracle
     import workloads
     from workloads import example_models
 
     spec = example_models.get(name)
     src, symdict = oracle.emit_c_source(workloads.model_for(name), **spec.compiler_kwargs)
-    return oracle.OracleModel(oracle.compile_c_model(src)), symdict
+    return oracle.OracleModel(oracle.compile_c_model(src, cc=cc)), symdict
 
 
 def compare(got, want, rtol, what=""):

@@ -11,12 +11,16 @@ Pipeline:
   2. run the reference's ``InflationModelBuilder.new(...).build(...)`` and
      ``Compiler(...)._generate_c_file()`` on the model definitions of
      ``workloads/example_models.py`` (the models of the reference's README/tests);
-  3. compile the reference-emitted C with gcc and the reference's flag list (into a temp dir);
-  4. evaluate it through oracle/sweep_oracle.c (the C restatement of the Rust sweep) on small
-     grids, adversarial points included, and store numbers only:
-        tests/golden/<model>.npz   args, extent, N0, N1, out (N0,N1,6), raw (N0,N1,5) + extras
+  3. compile the reference-emitted C with the reference's flag list (into a temp dir), once with gcc and once with
+     clang (the reference's compiler is ``zig cc`` = clang; gcc -std=c17 does not contract a*b+c, clang does);
+  4. evaluate both objects through oracle/sweep_oracle.c (the C restatement of the Rust sweep) on small
+     grids, adversarial points included, and store numbers only (``*_clang`` = the clang-built object):
+        tests/golden/<model>.npz   args, extent, N0, N1, out (N0,N1,6), raw (N0,N1,5), v01 (N0,N1) + extras
         tests/golden/symbols.json  per-model symbol tables, N_PARAMETERS, printer strings
 Nothing of the reference (source, generated C, binaries) is written into the repository.
+
+``--add`` keeps the stored numbers (and asserts that this run reproduces them bit for bit) and adds the keys that are
+missing; ``--basis`` writes basis.npz.
 """
 
 from __future__ import annotations
@@ -132,35 +136,74 @@ GRIDS = {
 }
 
 
-def main(models):
+def _reference_c(symbolic, compiler, name, tmp):
+    """The reference's own symbolic stage and C emitter for an example model -> (model, Compiler, path of the C file)."""
     import joblib
 
     from workloads import example_models
-    from oracle import OP, OracleModel
+
+    spec = example_models.get(name)
+    print(f"== {name}: reference symbolic stage", flush=True)
+    with joblib.parallel_backend("sequential"):
+        builder = symbolic.InflationModelBuilder.new(
+            spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
+        )
+        model = builder.build(spec.guesses)
+    c_path = os.path.join(tmp, f"{name}.c")
+    comp = compiler.Compiler(model, output_path=c_path, silent=True, **spec.compiler_kwargs)
+    with contextlib.redirect_stdout(open(os.devnull, "w")):
+        comp._generate_c_file()
+    return spec, model, comp, c_path
+
+
+def _build(c_path, cc_name, cc_path):
+    """The reference-emitted C built the way compiler.py:575-584 builds it, by one of the image's two C compilers."""
+    import subprocess
+
     from oracle.model_c import REFERENCE_FLAGS
+
+    so_path = c_path[:-2] + f".{cc_name}.so"
+    subprocess.run([cc_path, "-o", so_path, c_path, *REFERENCE_FLAGS], check=True)
+    return so_path
+
+
+def _sweeps(om, spec, ext, n0, n1):
+    """Everything a golden grid stores per compiler: the six outputs, the model values, the single quantities,
+    flag_quantum_dif at three accuracies, and the reference's own v01 (hesse_bindings.rs:202-210 loads it; lib.rs:384-420
+    returns it from `hesse`)."""
+    from oracle import OP, grid_points
+
+    res = {
+        "out": om.grid_sweep(OP.COMPLETE, spec.args, ext, n0, n1),
+        "raw": om.grid_sweep(OP.RAW, spec.args, ext, n0, n1),
+        "consistency": om.grid_sweep(OP.CONSISTENCY, spec.args, ext, n0, n1),
+        "rapidturn": om.grid_sweep(OP.RAPIDTURN, spec.args, ext, n0, n1),
+        "epsilon_v": om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1),
+    }
+    for accuracy in (1e-3, 0.5, 0.9):  # ops::flag_quantum_diff through the reference's C function `v`
+        res[f"qdif_{accuracy}"] = om.grid_sweep(OP.QDIF, spec.args, ext, n0, n1, accuracy=accuracy)
+    pts = grid_points(ext, n0, n1)
+    res["v01"] = np.array([om.hesse(x, spec.args)[0, 1] for x in pts]).reshape(n0, n1)
+    return res
+
+
+def main(models, add_only=False):
+    """``add_only``: keep the stored gcc-built numbers and 50-digit values (asserting that this run reproduces the
+    former bit for bit) and add what is missing -- the clang-built variants (``*_clang``) and ``*_v01``."""
+    from oracle import OracleModel
+    from oracle.model_c import reference_compilers
 
     symbolic, compiler = load_reference()
     sym_path = os.path.join(HERE, "symbols.json")
     symbols = json.load(open(sym_path)) if os.path.exists(sym_path) else {}
     tmp = tempfile.mkdtemp(prefix="inflx_golden_")
+    compilers = reference_compilers()
+    assert set(compilers) == {"gcc", "clang"}, compilers
 
     for name in models:
-        spec = example_models.get(name)
-        print(f"== {name}: reference symbolic stage", flush=True)
-        with joblib.parallel_backend("sequential"):
-            builder = symbolic.InflationModelBuilder.new(
-                spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
-            )
-            model = builder.build(spec.guesses)
-        c_path = os.path.join(tmp, f"{name}.c")
-        comp = compiler.Compiler(model, output_path=c_path, silent=True, **spec.compiler_kwargs)
-        with contextlib.redirect_stdout(open(os.devnull, "w")):
-            comp._generate_c_file()
-        so_path = os.path.join(tmp, f"{name}.so")
-        import subprocess
-
-        subprocess.run(["gcc", "-o", so_path, c_path, *REFERENCE_FLAGS], check=True)
-        om = OracleModel(so_path)
+        spec, model, comp, c_path = _reference_c(symbolic, compiler, name, tmp)
+        oms = {cc: OracleModel(_build(c_path, cc, path)) for cc, path in compilers.items()}
+        om = oms["gcc"]
         symbols[name] = {
             "symbol_dictionary": comp.symbol_dict,
             "n_parameters": int(om.n_parameters),
@@ -169,34 +212,37 @@ def main(models):
             "c_bytes": os.path.getsize(c_path),
         }
         assert om.n_parameters == len(spec.args), (om.n_parameters, spec.args)
-        out = {"args": spec.args}
+        npz = os.path.join(HERE, f"{name}.npz")
+        old = dict(np.load(npz)) if add_only else {}
+        out = dict(old) if add_only else {"args": spec.args}
         for tag, n0, n1, ext in GRIDS[name]:
             ext = np.array(ext if ext is not None else spec.extent, dtype=np.float64)
             out[f"{tag}_extent"] = ext
             out[f"{tag}_shape"] = np.array([n0, n1])
-            out[f"{tag}_out"] = om.grid_sweep(OP.COMPLETE, spec.args, ext, n0, n1)
-            out[f"{tag}_raw"] = om.grid_sweep(OP.RAW, spec.args, ext, n0, n1)
-            out[f"{tag}_consistency"] = om.grid_sweep(OP.CONSISTENCY, spec.args, ext, n0, n1)
-            out[f"{tag}_rapidturn"] = om.grid_sweep(OP.RAPIDTURN, spec.args, ext, n0, n1)
-            out[f"{tag}_epsilon_v"] = om.grid_sweep(OP.EPSILON_V, spec.args, ext, n0, n1)
-            for accuracy in (1e-3, 0.5, 0.9):  # ops::flag_quantum_diff through the reference's C function `v`
-                out[f"{tag}_qdif_{accuracy}"] = om.grid_sweep(OP.QDIF, spec.args, ext, n0, n1, accuracy=accuracy)
-            if tag in ("g16", "g64"):
+            for cc, suffix in (("gcc", ""), ("clang", "_clang")):
+                for key, arr in _sweeps(oms[cc], spec, ext, n0, n1).items():
+                    full = f"{tag}_{key}{suffix}"
+                    if full in old:  # the reference's stages gave the same C as when the stored numbers were made
+                        assert np.array_equal(old[full], arr, equal_nan=True), f"{name}: {full} is not reproduced"
+                    out[full] = arr
+            if tag in ("g16", "g64") and f"{tag}_raw_mp" not in out:
                 out[f"{tag}_raw_mp"] = mp_truth(model, comp.symbol_dict, spec.args, ext, n0, n1)
         if name == "doc":
             # the reference's only known-answer test on this path: tests/test_doc.py:50-51
             x = np.array([2.0, -2.0])
             out["kat_x"] = x
-            out["kat_V"] = np.array(om.potential(x, spec.args))
-            out["kat_H"] = om.hesse(x, spec.args)
-            assert out["kat_V"] == 1.9166666666666667
-            assert np.allclose(out["kat_H"], np.array([[0.41206897, -1.05517241], [-1.05517241, -0.07873563]]))
-            full = om.grid_sweep(OP.COMPLETE, spec.args, spec.extent, 1000, 1000, threads=8)
-            assert np.nanmax(full[:, :, 0]) <= 1  # tests/test_doc.py:58
-            out["full1000_nanmax_consistency"] = np.array(np.nanmax(full[:, :, 0]))
-        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+            for cc, suffix in (("gcc", ""), ("clang", "_clang")):
+                out[f"kat_V{suffix}"] = np.array(oms[cc].potential(x, spec.args))
+                out[f"kat_H{suffix}"] = oms[cc].hesse(x, spec.args)
+                assert out[f"kat_V{suffix}"] == 1.9166666666666667
+                assert np.allclose(out[f"kat_H{suffix}"], np.array([[0.41206897, -1.05517241], [-1.05517241, -0.07873563]]))
+                full = oms[cc].grid_sweep(0, spec.args, spec.extent, 1000, 1000, threads=8)
+                assert np.nanmax(full[:, :, 0]) <= 1  # tests/test_doc.py:58
+                out[f"full1000_nanmax_consistency{suffix}"] = np.array(np.nanmax(full[:, :, 0]))
+        np.savez_compressed(npz, **out)
         print(f"   wrote {name}.npz; symbols = {comp.symbol_dict}", flush=True)
-        om.close()
+        for m in oms.values():
+            m.close()
 
     # printer known-answer strings (reference tests/test_compiler.py:40-53 hold the expected text)
     import sympy
@@ -223,31 +269,15 @@ def basis_goldens(models):
     """tests/golden/basis.npz: the reference's C functions ``v``, ``w1`` and ``inner_prod`` (what
     validate_basis_* calls, src/lib.rs:141-300) at seeded points -- 64 inside the model's extent at the
     model's own parameters, and the 100 points in [-1,1)^2 with one parameter vector in [-10,10) that a
-    ``validate_basis_at_random`` run would draw."""
-    import subprocess
-
-    import joblib
-
-    from workloads import example_models
+    ``validate_basis_at_random`` run would draw -- as gcc builds them and (``*_clang``) as clang does."""
     from oracle.cpu_oracle import basis_on_points
-    from oracle.model_c import REFERENCE_FLAGS
+    from oracle.model_c import reference_compilers
 
     symbolic, compiler = load_reference()
     tmp = tempfile.mkdtemp(prefix="inflx_golden_")
     out = {}
     for name in models:
-        spec = example_models.get(name)
-        print(f"== {name}: reference symbolic stage", flush=True)
-        with joblib.parallel_backend("sequential"):
-            builder = symbolic.InflationModelBuilder.new(
-                spec.fields, spec.metric, spec.potential, model_name=name, init_sympy_printing=False, **spec.builder_kwargs
-            )
-            model = builder.build(spec.guesses)
-        c_path, so_path = os.path.join(tmp, f"{name}.c"), os.path.join(tmp, f"{name}.so")
-        comp = compiler.Compiler(model, output_path=c_path, silent=True, **spec.compiler_kwargs)
-        with contextlib.redirect_stdout(open(os.devnull, "w")):
-            comp._generate_c_file()
-        subprocess.run(["gcc", "-o", so_path, c_path, *REFERENCE_FLAGS], check=True)
+        spec, model, comp, c_path = _reference_c(symbolic, compiler, name, tmp)
         rng = np.random.default_rng(20250216 + len(name))
         x0a, x0b, x1a, x1b = spec.extent
         inside = np.stack([rng.uniform(x0a, x0b, 64), rng.uniform(x1a, x1b, 64)], axis=1)
@@ -255,18 +285,28 @@ def basis_goldens(models):
         p_rand = rng.uniform(-10.0, 10.0, len(spec.args))
         out[f"{name}_args"] = np.asarray(spec.args, dtype=np.float64)
         out[f"{name}_inside_x"] = inside
-        out[f"{name}_inside_basis"] = basis_on_points(so_path, spec.args, inside)
         out[f"{name}_unit_x"] = unit
         out[f"{name}_unit_p"] = p_rand
-        out[f"{name}_unit_basis"] = basis_on_points(so_path, p_rand, unit)
-        out[f"{name}_unit_basis_args"] = basis_on_points(so_path, spec.args, unit)
+        for cc, path in reference_compilers().items():
+            so_path = _build(c_path, cc, path)
+            suffix = "" if cc == "gcc" else f"_{cc}"
+            out[f"{name}_inside_basis{suffix}"] = basis_on_points(so_path, spec.args, inside)
+            out[f"{name}_unit_basis{suffix}"] = basis_on_points(so_path, p_rand, unit)
+            out[f"{name}_unit_basis_args{suffix}"] = basis_on_points(so_path, spec.args, unit)
         print(f"   {name}: inside-extent norms {np.nanmin(out[f'{name}_inside_basis'][:, 0]):.6f}..{np.nanmax(out[f'{name}_inside_basis'][:, 0]):.6f}", flush=True)
-    np.savez_compressed(os.path.join(HERE, "basis.npz"), **out)
+    old_path = os.path.join(HERE, "basis.npz")
+    if os.path.exists(old_path):  # the stored gcc numbers must come out again
+        old = dict(np.load(old_path))
+        for key, arr in old.items():
+            if key in out:
+                assert np.array_equal(arr, out[key], equal_nan=True), f"basis.npz: {key} is not reproduced"
+    np.savez_compressed(old_path, **out)
     print("wrote basis.npz")
 
 
 if __name__ == "__main__":
+    names = [a for a in sys.argv[1:] if not a.startswith("--")]
     if "--basis" in sys.argv[1:]:
-        basis_goldens([a for a in sys.argv[1:] if a != "--basis"] or list(GRIDS))
+        basis_goldens(names or list(GRIDS))
     else:
-        main(sys.argv[1:] or list(GRIDS))
+        main(names or list(GRIDS), add_only="--add" in sys.argv[1:])

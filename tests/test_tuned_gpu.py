@@ -31,6 +31,7 @@ def tuned_devlib(name, gpu_lib):
 @pytest.fixture
 def tuned(monkeypatch):
     monkeypatch.setattr(T, "devlib", tuned_devlib)
+    monkeypatch.setattr(T, "BUILD", ["profile-guided"])
 
 
 @pytest.mark.parametrize("name", TUNED)

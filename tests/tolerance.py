@@ -88,7 +88,8 @@ def single_quantities(raw: np.ndarray) -> dict:
 
 @functools.lru_cache(maxsize=None)
 def _models(name):
-    """(double oracle model, path of the long-double model object) for an example model."""
+    """({compiler: double oracle model}, path of the long-double model object) for an example model: the reference's C as
+    gcc builds it and as clang builds it (oracle.reference_compilers), and its x87 extended-precision twin."""
     import oracle
     import workloads
     from workloads import example_models
@@ -97,19 +98,22 @@ def _models(name):
     m = workloads.model_for(name)
     src, _ = oracle.emit_c_source(m, **spec.compiler_kwargs)
     src_ld, _ = oracle.emit_c_source(m, long_double=True, **spec.compiler_kwargs)
-    return oracle.OracleModel(oracle.compile_c_model(src)), oracle.compile_c_model(src_ld)
+    doubles = {cc: oracle.OracleModel(oracle.compile_c_model(src, cc=cc)) for cc in oracle.reference_compilers()}
+    return doubles, oracle.compile_c_model(src_ld)
 
 
 def reference_error(name, p, pts, copies: int = 12, seed: int = 1234):
     """Returns ``(E, flaky)`` for the five model values at the (n,2) points.
 
-    E: max over the point and `copies` few-ulp moves of it of |float64 reference - extended-precision
-    reference|; inf where either is not finite.  flaky: the reference's NaN-ness itself is not robust
-    there (it differs between the copies, or between float64 and extended precision -- e.g. the square
-    root of a cancelling quantity that rounds to -1e-20 in one evaluation and +1e-20 in another)."""
+    E: max over the point and `copies` few-ulp moves of it, AND over the two C compilers that stand in for the
+    reference's `zig cc` (gcc: no contraction under -std=c17; clang: a*b+c inside an expression becomes an FMA), of
+    |float64 reference - extended-precision reference|; inf where either is not finite.  flaky: the reference's
+    NaN-ness itself is not robust there (it differs between the copies, between the two compilers, or between float64
+    and extended precision -- e.g. the square root of a cancelling quantity that rounds to -1e-20 in one evaluation and
+    +1e-20 in another)."""
     import oracle
 
-    om, ld_path = _models(name)
+    doubles, ld_path = _models(name)
     pts = np.ascontiguousarray(pts, dtype=np.float64).reshape(-1, 2)
     rng = np.random.default_rng(seed)
     env = np.zeros((pts.shape[0], 5))
@@ -117,15 +121,16 @@ def reference_error(name, p, pts, copies: int = 12, seed: int = 1234):
     flaky = np.zeros((pts.shape[0], 5), dtype=bool)
     for q in range(copies + 1):
         moved = pts if q == 0 else pts * (1.0 + EPS * rng.integers(-8, 9, size=pts.shape))
-        a = om.trajectory_sweep(oracle.OP.RAW, p, moved)
         t = oracle.raw_long_double(ld_path, p, moved)
-        with np.errstate(all="ignore"):
-            e = np.abs(a - t)
-        e[~(np.isfinite(a) & np.isfinite(t))] = np.inf
-        env = np.maximum(env, e)
-        nan_count += np.isnan(a)
-        flaky |= np.isnan(a) != np.isnan(t)
-    flaky |= (nan_count > 0) & (nan_count < copies + 1)
+        for om in doubles.values():
+            a = om.trajectory_sweep(oracle.OP.RAW, p, moved)
+            with np.errstate(all="ignore"):
+                e = np.abs(a - t)
+            e[~(np.isfinite(a) & np.isfinite(t))] = np.inf
+            env = np.maximum(env, e)
+            nan_count += np.isnan(a)
+            flaky |= np.isnan(a) != np.isnan(t)
+    flaky |= (nan_count > 0) & (nan_count < (copies + 1) * len(doubles))
     return env, flaky
 
 
@@ -169,8 +174,8 @@ def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn, model: str | Non
 STATS = []  # one record per check() call: what, compared values, excluded fraction, worst ratio (conftest dumps it)
 
 
-def check(got, ref, allowed, flaky=None, what="", model: str | None = None):
-    """NaN pattern exact, +-Inf exact (with sign), finite values within `allowed`.  `flaky` marks the
+def check(got, ref, allowed, flaky=None, what="", model: str | None = None, against: str | None = None):
+    """`against`: which build of the reference `ref` is ("gcc" / "clang"), for the statistics.  NaN pattern exact, +-Inf exact (with sign), finite values within `allowed`.  `flaky` marks the
     points where the reference's own NaN-ness is not robust (see reference_error); the NaN/Inf pattern
     is not compared there.  The fraction of values left out of the value comparison (infinite allowance, or
     flaky) is bounded by EXCLUDED_CAP_BY_MODEL.  Returns the largest |got-ref| / allowed over the compared
@@ -181,7 +186,9 @@ def check(got, ref, allowed, flaky=None, what="", model: str | None = None):
     loose = np.isfinite(ref) & ~np.isfinite(np.broadcast_to(allowed, ref.shape))
     excluded = float((loose | ~firm).sum()) / max(1, ref.size)
     cap = EXCLUDED_CAP_BY_MODEL.get(model, EXCLUDED_CAP)
-    record = {"what": what, "model": model, "values": int(ref.size), "excluded": excluded, "worst_ratio": None}
+    record = {"what": what, "model": model, "against": against, "values": int(ref.size), "excluded": excluded, "worst_ratio": None}
+    if flaky is not None:  # at the points whose NaN-ness the reference itself does not settle: how often is the GPU's the same as this build's?
+        record["nan_mismatch_at_flaky_points"] = int((np.isnan(got) != np.isnan(ref))[~firm].sum())
     STATS.append(record)
     assert excluded <= cap, f"{what}: {100 * excluded:.2f} % of the values are outside the value comparison (cap {100 * cap:.2f} %)"
     assert np.array_equal(np.isnan(got)[firm], np.isnan(ref)[firm]), f"{what}: NaN pattern differs"
@@ -201,14 +208,41 @@ def check(got, ref, allowed, flaky=None, what="", model: str | None = None):
     return worst
 
 
+def reference_pair(ref_a, ref_b, allowed, flaky=None, what="", model: str | None = None, got=None):
+    """The reference against ITSELF: the gcc-built numbers against the clang-built ones under the allowance the GPU is
+    held to.  Nothing is asserted -- this is the measure of what the criterion asks for: a ratio near or above 1 says that
+    the reference's two builds are as far from each other as the GPU may be from either.  Recorded next to the GPU's
+    own ratios (profiles/r05_parity_stats.json).  With `got`: where the two builds disagree about NaN, whose side the GPU
+    takes."""
+    ref_a, ref_b, allowed = np.asarray(ref_a), np.asarray(ref_b), np.asarray(allowed)
+    firm = np.ones(ref_a.shape, dtype=bool) if flaky is None else ~np.broadcast_to(flaky, ref_a.shape)
+    nan_diff = np.isnan(ref_a) != np.isnan(ref_b)
+    record = {"what": what, "model": model, "against": "gcc-vs-clang", "values": int(ref_a.size), "worst_ratio": None,
+              "nan_mismatch": int(nan_diff.sum()), "nan_mismatch_at_firm_points": int((nan_diff & firm).sum())}
+    if got is not None and nan_diff.any():
+        got = np.asarray(got)
+        record["gpu_nan_like_gcc"] = int((np.isnan(got) == np.isnan(ref_a))[nan_diff].sum())
+        record["gpu_nan_like_clang"] = int((np.isnan(got) == np.isnan(ref_b))[nan_diff].sum())
+    fin = np.isfinite(ref_a) & np.isfinite(ref_b) & np.isfinite(np.broadcast_to(allowed, ref_a.shape)) & firm
+    if fin.any():
+        with np.errstate(all="ignore"):
+            ratio = np.abs(ref_a[fin] - ref_b[fin]) / np.maximum(np.broadcast_to(allowed, ref_a.shape)[fin], np.finfo(float).tiny)
+            rel = np.abs(ref_a[fin] - ref_b[fin]) / np.maximum(np.abs(ref_a[fin]), np.finfo(float).tiny)
+        record["worst_ratio"] = float(ratio.max())
+        record["above_1e-10"] = int((rel > RTOL).sum())
+        record["max_rel"] = float(rel.max())
+    STATS.append(record)
+    return record
+
+
 # ---- basis validation (tests/test_basis.py, tests/test_parity_gpu.py) --------------------------------
-def basis_sensitivity(name, p, pts, want):
+def basis_sensitivity(name, p, pts, want, cc="gcc"):
     """How much the reference's own numbers move when the point moves by a few ulps: the measure of its
     rounding error at ill-conditioned points (the angular model's basis cancels to ~1e-6 there)."""
     from conftest import oracle_model
     from oracle import cpu_oracle
 
-    om, _ = oracle_model(name)
+    om, _ = oracle_model(name, cc)
     rng = np.random.default_rng(11)
     spread = np.zeros_like(want)
     for _ in range(8):
