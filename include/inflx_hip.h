@@ -49,8 +49,12 @@ typedef enum inflx_op {
   INFLX_SWEEP_CONSISTENCY = 1, /* ops::consistency_only           anguelova.rs:157-163, 1 f64/point */
   INFLX_SWEEP_RAPIDTURN = 2,   /* ops::consistency_rapidturn_only anguelova.rs:143-154, 1 f64/point */
   INFLX_SWEEP_EPSILON_V = 3,   /* ops::epsilon_v_only             anguelova.rs:138-140, 1 f64/point */
-  INFLX_SWEEP_RAW = 4          /* V,v00,v10,v11,|dV|^2 (diagnostic, 5 f64/point; what Potential /
+  INFLX_SWEEP_RAW = 4,         /* V,v00,v10,v11,|dV|^2 (diagnostic, 5 f64/point; what Potential /
                                   Hesse2D return, hesse_bindings.rs:52-57,106-110,213-231)          */
+  INFLX_SWEEP_HESSE = 6        /* v00,v01,v10,v11 (4 f64/point): the projected Hesse matrix row-major, what `hesse` /
+                                  `hesse_array` return (src/lib.rs:384-462) -- v01 is the reference's own v01 expression
+                                  (hesse_bindings.rs:202-210), evaluated on its own wherever it is not the very expression
+                                  of v10                                                             */
 } inflx_op;
 
 typedef enum inflx_layout {

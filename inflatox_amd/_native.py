@@ -20,7 +20,8 @@ LIB_PATH = os.path.join(_PKG, "libinflx_hip.so")
 OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG, ERR_BASIS = range(8)
 
 OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
-OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5}
+OP_HESSE = 6  # v00, v01, v10, v11: the projected Hesse matrix with the reference's own v01 (INFLX_SWEEP_HESSE)
+OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5, OP_HESSE: 4}
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
 
 _DP = C.POINTER(C.c_double)

@@ -52,11 +52,11 @@ class InflationCondition:
         return float(self._raw_at(x, args)[0])
 
     def calc_H(self, x: np.ndarray, args: np.ndarray) -> np.ndarray:
-        """Projected Hesse matrix at ``x``.  The sweep kernels carry v00, v10, v11 only (Hesse2D never
-        calls v01, hesse_bindings.rs:213-231); the matrix is symmetric, so v01 is filled from v10."""
-        r = self._raw_at(x, args)
-        return np.array([[r[1], r[2]], [r[2], r[3]]])
-
+        """Projected Hesse matrix at ``x``: ``[[v00, v01], [v10, v11]]`` like the reference's ``hesse`` (src/lib.rs:384-420),
+        every component the value of the reference's own C function of that name -- v01 included: it is evaluated on its own
+        wherever its expression is not, node for node, the expression of v10 (``INFLX_OP_HESSE``)."""
+        x = np.asarray(x, dtype=np.float64).reshape(1, 2)
+        return self.dylib.sweep_on_trajectory(_native.OP_HESSE, args, x)[0].reshape(2, 2)
 
     # -- array helpers (reference :67-101,119-156); off the sweep path, served by the raw-values sweep ----
     def _raw_planes(self, args, x0_start, x0_stop, x1_start, x1_stop, N, first, count):
@@ -73,14 +73,13 @@ class InflationCondition:
     def calc_H_array(self, args, x0_start, x0_stop, x1_start, x1_stop, N=None) -> np.ndarray:
         """Projected Hesse matrix on the grid, shape (2, 2, N0, N1) as the reference documents
         (consistency_conditions.py:119-156; its implementation passes the wrong arguments to the native
-        helper and cannot run, so the documented contract is what is implemented).  v01 is v10 (the sweep kernels carry v10
-        only): the result is a read-only view in which ``H[0, 1]`` and ``H[1, 0]`` are the same memory."""
-        hess = self._raw_planes(args, x0_start, x0_stop, x1_start, x1_stop, N, 1, 3)  # v00, v10, v11
-        # H[a, b] is plane a + b of those three: a strided view, not a copy -- at the default 8000 x 8000 grid four planes would be
-        # 2 GB.  H[0, 1] and H[1, 0] are the same memory (the matrix is symmetric), so the view is read-only; ``.copy()`` gives an
-        # independent array.
-        plane = hess.strides[0]
-        return np.lib.stride_tricks.as_strided(hess, shape=(2, 2) + hess.shape[1:], strides=(plane, plane) + hess.strides[1:], writeable=False)
+        helper and cannot run, so the documented contract is what is implemented): an ordinary writable array whose
+        ``H[a, b]`` is the plane of the reference's C function ``v{a}{b}`` -- ``H[0, 1]`` the reference's own v01, in memory of
+        its own (``INFLX_OP_HESSE``, four planes; 2 GB at the default 8000 x 8000 grid, as in the reference)."""
+        n0, n1 = (int(v) for v in (N if N is not None else (8000, 8000)))
+        ss = _start_stop(x0_start, x0_stop, x1_start, x1_stop)
+        planes = self.dylib.sweep_host(_native.OP_HESSE, args, ss, n0, n1, layout=_native.LAYOUT_SOA)  # (4, N0, N1): v00, v01, v10, v11
+        return planes.reshape(2, 2, n0, n1)
 
     def validate_basis_on_domain(self, args, start, stop, N=100, accuracy: float = 1e-3) -> None:
         """Checks that the basis {v, w1} is orthonormal (to ``accuracy``) on sample points of the domain

@@ -58,10 +58,10 @@ int fail(int code, const char* fmt, ...) {
   } while (0)
 
 constexpr uint16_t kAbiMajor = 5, kAbiMinor = 0;  // src/lib.rs:50 V_INFLX_ABI
-const char* const kOpNames[INFLX_OP_COUNT] = {"complete", "consistency", "rapidturn", "epsilon_v", "raw", "qdif"};
-constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5, 1};
+const char* const kOpNames[INFLX_OP_COUNT] = {"complete", "consistency", "rapidturn", "epsilon_v", "raw", "qdif", "hesse"};
+constexpr int kOpWidth[INFLX_OP_COUNT] = {6, 1, 1, 1, 5, 1, 4};
 // bytes per grid point of an operation's result (the flag sweep writes one bool per point)
-constexpr size_t kOpBytes[INFLX_OP_COUNT] = {48, 8, 8, 8, 40, 1};
+constexpr size_t kOpBytes[INFLX_OP_COUNT] = {48, 8, 8, 8, 40, 1, 32};
 
 // device chunk used by the host-result path: two buffers of this many bytes at most
 size_t chunk_bytes_limit() {

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 16u
+#define INFLX_KERNEL_ABI 17u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -13,7 +13,10 @@ enum InflxOp {
   INFLX_OP_EPSILON_V = 3,    // ops::epsilon_v_only             1 f64
   INFLX_OP_RAW = 4,          // V, v00, v10, v11, |dV|^2        5 f64 (diagnostic; pins the model functions)
   INFLX_OP_QDIF = 5,         // ops::flag_quantum_diff          1 byte (bool) per point
-  INFLX_OP_COUNT = 6
+  INFLX_OP_HESSE = 6,        // v00, v01, v10, v11              4 f64: the projected Hesse matrix row-major, with the reference's
+                             //                                 OWN v01 (Hesse2D loads fns=[v00,v01,v10,v11], hesse_bindings.rs:202-210;
+                             //                                 `hesse` returns all four, src/lib.rs:384-420)
+  INFLX_OP_COUNT = 7
 };
 
 // output memory layout for multi-value operations

@@ -16,6 +16,7 @@ struct InflxModelValues {
   double g;    // |grad V|^2                       (C symbol `grad_norm_squared`)
   double b0;   // basis vector v, component 0      (C symbol `v`, v_out[0]; Potential::grad)
   double b1;   // basis vector v, component 1      (v_out[1])
+  double v01;  // Hesse component along (v, w)     (C symbol `v01`; filled for INFLX_OP_HESSE only -- Hesse2D never calls it on a sweep)
 };
 
 // atan and tan of the epilogue (src/anguelova.rs:128,132: f64::atan / f64::tan, i.e. the platform libm).  On the
@@ -362,6 +363,41 @@ INFLX_FN double inflx_op_consistency_only(const InflxModelValues& m) {
   const double lhs = m.v11 / m.V - 3.;
   const double rhs = 3. * inflx_sq(m.v00 / m.v10) + (m.v00 / m.V) * inflx_sq(m.v10 / m.v00);
   return fabs(fabs(lhs) - fabs(rhs)) / (fabs(lhs) + fabs(rhs));
+}
+
+// ops::consistency_only with its five divisions spelled as inflx_quotient (see inflx_op_complete_analysis_quick): one
+// reciprocal of V serves v11/V and v00/V, and no division carries its special-case handling -- 4 reciprocals + 5 x 3
+// instructions instead of 5 x 11.  Returns whether the point qualified (else `out` is unspecified and the caller evaluates
+// inflx_op_consistency_only).  Mid-range, division by division, for V, v00, v10, v11 normal with 2^-120 <= |x| < 2^121
+// (a = numerator, b = denominator, q = quotient; needed: b and 1/b normal, |a| >= 2^-969 or a = +0, q normal or +0):
+//   v11/V, v00/v10, v10/v00, v00/V     a, b in range, |q| in (2^-241, 2^241)
+//   num / den, num = ||lhs| - |rhs||, den = |lhs| + |rhs|, lhs = v11/V - 3, rhs = 3 (v00/v10)^2 + (v00/V)(v10/v00)^2:
+//     |lhs| is 0 or >= 2^-51 (a quotient within a factor 2 of 3 is a multiple of 2^-51) and < 2^242; |rhs| is 0 or
+//     >= 2^-775 (a sum of multiples of 2^-775) and < 2^725; so den is 0 -- tested on its own -- or in [2^-775, 2^726): b and 1/b
+//     normal.  With L >= S the two magnitudes: L >= 2 S gives num >= L/2 and q >= 1/4; else num = L - S is exact, 0 or >=
+//     ulp(S)/2 >= 2^-53 S >= 2^-828, and q is +0 or >= 2^-53 S / (3 S) > 2^-55.
+// (consistency_rapidturn_only has three divisions and no shared denominator: the range test would cost what the three
+// fix-ups save, so it keeps the compiler's divisions.)
+INFLX_FN bool inflx_op_consistency_only_quick(const InflxModelValues& m, double& out) {
+#ifdef INFLX_HOST_TWIN
+  out = inflx_op_consistency_only(m);
+  return true;
+#else
+#pragma clang fp contract(off)
+  const double v = m.V, v11 = m.v11, v10 = m.v10, v00 = m.v00;
+  const unsigned e0 = inflx_exponent_field(v), e1 = inflx_exponent_field(v11), e2 = inflx_exponent_field(v10), e3 = inflx_exponent_field(v00);
+  const unsigned lowest = min(min(e0, e1), min(e2, e3)), highest = max(max(e0, e1), max(e2, e3));
+  bool ok = lowest >= 1023u - 120u && highest <= 1023u + 120u;
+  const double yv = inflx_rcp_newton2(v);
+  const double a_over_b = inflx_quotient(v00, v10, inflx_rcp_newton2(v10));
+  const double b_over_a = inflx_quotient(v10, v00, inflx_rcp_newton2(v00));
+  const double lhs = inflx_quotient(v11, v, yv) - 3.;
+  const double rhs = 3. * inflx_sq(a_over_b) + inflx_quotient(v00, v, yv) * inflx_sq(b_over_a);
+  const double num = fabs(fabs(lhs) - fabs(rhs)), den = fabs(lhs) + fabs(rhs);
+  ok = ok && den != 0.0;
+  out = inflx_quotient(num, den, inflx_rcp_newton2(den));
+  return ok;
+#endif
 }
 
 // ops::flag_quantum_diff, src/anguelova.rs:166-170: all components of the normalised gradient

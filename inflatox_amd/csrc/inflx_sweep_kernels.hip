@@ -111,7 +111,7 @@ INFLX_EXPORT InflxKernelInfo INFLX_KERNEL_INFO = {
 
 template <int OP>
 struct OpWidth {
-  static constexpr int K = (OP == INFLX_OP_COMPLETE) ? 6 : (OP == INFLX_OP_RAW ? 5 : 1);
+  static constexpr int K = (OP == INFLX_OP_COMPLETE) ? 6 : (OP == INFLX_OP_RAW ? 5 : (OP == INFLX_OP_HESSE ? 4 : 1));
 };
 
 // TABLE / `kc`: the polynomial coefficients of the epilogue's atan / tan come from a table in LDS (tile kernels) instead
@@ -128,6 +128,11 @@ __device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, 
     o[0] = inflx_op_consistency_rapidturn_only(mv);
   } else if constexpr (OP == INFLX_OP_EPSILON_V) {
     o[0] = inflx_op_epsilon_v_only(mv);
+  } else if constexpr (OP == INFLX_OP_HESSE) {
+    o[0] = mv.v00;
+    o[1] = mv.v01;
+    o[2] = mv.v10;
+    o[3] = mv.v11;
   } else {
     o[0] = mv.V;
     o[1] = mv.v00;
@@ -137,14 +142,33 @@ __device__ __forceinline__ void apply_op(const InflxModelValues& mv, double* o, 
   }
 }
 
+// INFLX_OP_HESSE: the reference's own v01 (`hesse`, src/lib.rs:384-420, returns [v00, v01, v10, v11]).  Where the symbolic stage
+// gave v01 the very expression of v10 (INFLX_V01_IS_V10: every example model -- sympy's canonical form of the symmetric
+// projection) the value IS v10, bit for bit; otherwise the generated header carries v01 as a function of its own, printed and
+// evaluated like the reference's C function (its own stages inline, once per point: this is a helper off the sweep path).
+template <int OP>
+__device__ __forceinline__ void fill_v01([[maybe_unused]] InflxModelValues& mv, [[maybe_unused]] double x0, [[maybe_unused]] double x1,
+                                         [[maybe_unused]] const double* A) {
+  if constexpr (OP == INFLX_OP_HESSE) {
+#if INFLX_V01_IS_V10
+    mv.v01 = mv.v10;
+#else
+    mv.v01 = inflx_v01_point(x0, x1, A);
+#endif
+  }
+}
+
 // The per-point operation with its divisions spelled without special-case handling (inflx_ops.h); false = this point
-// needs the IEEE spelling.  Only complete_analysis has such a variant: the single-quantity operations are three or four
-// divisions on an 8-byte store stream.
+// needs the IEEE spelling.  complete_analysis (eleven divisions) and consistency_only (five, two of them by V) have such
+// a variant; consistency_rapidturn_only (three divisions, no shared denominator) and epsilon_v_only (one) would pay as much
+// for the range test as the fix-ups cost.
 template <int OP, bool TABLE = false>
 __device__ __forceinline__ bool apply_op_quick(const InflxModelValues& mv, double* o, [[maybe_unused]] double accuracy = 0.0, [[maybe_unused]] const double* kc = nullptr) {
 #ifndef INFLX_EXPERIMENT_IEEE_EPILOGUE  // (A/B experiments: the compiler's divisions in the hot loop as well)
   if constexpr (OP == INFLX_OP_COMPLETE) {
     return inflx_op_complete_analysis_quick<TABLE>(mv, o, kc);
+  } else if constexpr (OP == INFLX_OP_CONSISTENCY) {
+    return inflx_op_consistency_only_quick(mv, o[0]);
   } else
 #endif
   {
@@ -468,6 +492,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #else
     inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
 #endif
+    fill_v01<OP>(mv, x0, x1, A);
     double o[K];
     ok = apply_op_quick<OP, kTable>(mv, o, a.accuracy, kc) && ok;
     // (lanes past N1 hold zeros for their column values and fail every acceptance test: they do not vote)
@@ -491,6 +516,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #else
     inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
 #endif
+    fill_v01<OP>(mv, x0, x1, A);
     double o[K];
     apply_op<OP, kTable>(mv, o, a.accuracy, kc);
     emit(o, row);
@@ -513,6 +539,7 @@ __device__ __forceinline__ void eval_row(const InflxSweepArgs& a, unsigned p, ui
   // by construction of the row kernels nothing below reads x1 or C
   InflxModelValues mv;
   inflx_stage_point(x0, a.x1a, A, U, R, C, mv);
+  fill_v01<OP>(mv, x0, a.x1a, A);
   apply_op<OP>(mv, o, a.accuracy);
 }
 
@@ -681,6 +708,7 @@ __device__ __forceinline__ void sweep_colvals(const InflxSweepArgs& a) {
     inflx_stage_col(x1, A, U, C);
     InflxModelValues mv;
     inflx_stage_point(x0, x1, A, U, R, C, mv);
+    fill_v01<OP>(mv, x0, x1, A);
     apply_op<OP>(mv, o, a.accuracy);
   }
   if constexpr (STATS) {
@@ -732,6 +760,7 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
   inflx_stage_col(x1, A, U, C);
   InflxModelValues mv;
   inflx_stage_point(x0, x1, A, U, R, C, mv);
+  fill_v01<OP>(mv, x0, x1, A);
   double o[K];
   apply_op<OP>(mv, o, a.accuracy);
 #pragma unroll
@@ -834,11 +863,16 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_ops_on_values(const
   bool ok = false;
   if (a.reserved == 0) ok = apply_op_quick<INFLX_OP_COMPLETE>(mv, o);
   if (__builtin_amdgcn_ballot_w64(!ok && live) != 0) apply_op<INFLX_OP_COMPLETE>(mv, o);
+  // consistency_only the way the tile kernel evaluates it: the quick spelling, the IEEE one for the whole wavefront otherwise
+  double cons;
+  bool ok_cons = false;
+  if (a.reserved == 0) ok_cons = apply_op_quick<INFLX_OP_CONSISTENCY>(mv, &cons);
+  if (__builtin_amdgcn_ballot_w64(!ok_cons && live) != 0) cons = inflx_op_consistency_only(mv);
   if (!live) return;
   double* dst = a.out + idx * 9;
 #pragma unroll
   for (int k = 0; k < 6; ++k) dst[k] = o[k];
-  dst[6] = inflx_op_consistency_only(mv);
+  dst[6] = cons;
   dst[7] = inflx_op_consistency_rapidturn_only(mv);
   dst[8] = inflx_op_epsilon_v_only(mv);
 }
@@ -868,3 +902,4 @@ INFLX_DEFINE_KERNELS(rapidturn, INFLX_OP_RAPIDTURN)
 INFLX_DEFINE_KERNELS(epsilon_v, INFLX_OP_EPSILON_V)
 INFLX_DEFINE_KERNELS(raw, INFLX_OP_RAW)
 INFLX_DEFINE_KERNELS(qdif, INFLX_OP_QDIF)
+INFLX_DEFINE_KERNELS(hesse, INFLX_OP_HESSE)

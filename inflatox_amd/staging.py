@@ -877,6 +877,8 @@ def emit_stage_header(
         out.append(point_body)
         out.append("}\n")
     out.append(_emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector))
+    v01_text, v01_is_v10 = _emit_v01_point(model, exprs[2], x0, x1, names, param_slots, tail, cse)
+    out.append(v01_text)
     sweep_lines = "\n".join(ln for ln in point_body.splitlines() if not ln.lstrip().startswith(("mv.b0", "mv.b1")))
     info = dict(
         nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()},
@@ -885,8 +887,41 @@ def emit_stage_header(
         shared_quotients=sweep_lines.count("INFLX_DIVS("),
         shared_reciprocals=sweep_lines.count("INFLX_RCPN("),
         quick_square_roots=sweep_lines.count("INFLX_SQRT(") + sweep_lines.count("INFLX_HPOW("),
+        v01_is_v10=bool(v01_is_v10),
     )  # fmt: skip
     return "\n".join(out), info
+
+
+def _emit_v01_point(model, v10_expr, x0, x1, names, param_slots, tail, cse):
+    """The reference's C function ``v01`` (compiler.py:498-504; Hesse2D loads it, hesse_bindings.rs:202-210, and `hesse` /
+    `hesse_array` return it, src/lib.rs:384-462) for the INFLX_OP_HESSE kernels behind ``calc_H`` / ``calc_H_array``.
+
+    The projected Hesse matrix is symmetric, and for every example model sympy gives ``hesse_cmp[0][1]`` the very same
+    expression tree as ``hesse_cmp[1][0]``: same tree, same printed C, same bits -- then ``INFLX_V01_IS_V10`` is 1 and the
+    kernels return the staged v10.  A symbolic stage that leaves the two components in different forms (a simplification
+    that timed out on one of them, a hand-made model) makes the reference evaluate two different C functions; then v01 is
+    emitted here as a function of its own: staged like the sweep values (identical nodes once, pow chains), all four
+    stages inline and evaluated per point -- a helper off the sweep path, exact in the sense of the module docstring."""
+    v01 = sympy.sympify(model.hesse_cmp[0][1])
+    if v01 == v10_expr:
+        return "// v01 is, node for node, the expression of v10 (symmetric projection): the kernels return the staged v10\n#define INFLX_V01_IS_V10 1\n", True
+    plain = C99CodePrinter()._print_Symbol
+    names = dict(names)
+    for sym in v01.free_symbols - {x0, x1}:
+        names[sym] = param_slots[plain(sym)]
+    if cse is not None:
+        repl, red = cse(v01)
+        functions = [(repl, [red])]
+    else:
+        functions = [([], [v01])]
+    st = Stager(functions, x0, x1, names, staged=True)
+    lines = [ln for m in (U, R, C, P) for ln in st.lines[m]]
+    head = (
+        "// the reference's C function v01: its own expression, every stage inline (INFLX_OP_HESSE only)\n"
+        "#define INFLX_V01_IS_V10 0\n"
+        f"INFLX_FN double inflx_v01_point([[maybe_unused]] const double x0, [[maybe_unused]] const double x1, {tail}) {{"
+    )
+    return head + "\n" + "\n".join(lines) + f"\n  return {st.outputs[0]};\n}}\n", False
 
 
 def _emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector):

@@ -40,7 +40,7 @@ static constexpr int kNU = INFLX_NU > 0 ? INFLX_NU : 1;
 static constexpr int kNR = INFLX_NR > 0 ? INFLX_NR : 1;
 static constexpr int kNC = INFLX_NC > 0 ? INFLX_NC : 1;
 
-static int width(int op) { return op == INFLX_OP_COMPLETE ? 6 : (op == INFLX_OP_RAW ? 5 : 1); }
+static int width(int op) { return op == INFLX_OP_COMPLETE ? 6 : (op == INFLX_OP_RAW ? 5 : (op == INFLX_OP_HESSE ? 4 : 1)); }
 
 static double g_accuracy = 0.0;
 static void apply(int op, const InflxModelValues& mv, double* o) {
@@ -50,13 +50,25 @@ static void apply(int op, const InflxModelValues& mv, double* o) {
     case INFLX_OP_CONSISTENCY: o[0] = inflx_op_consistency_only(mv); break;
     case INFLX_OP_RAPIDTURN: o[0] = inflx_op_consistency_rapidturn_only(mv); break;
     case INFLX_OP_EPSILON_V: o[0] = inflx_op_epsilon_v_only(mv); break;
+    case INFLX_OP_HESSE: o[0] = mv.v00; o[1] = mv.v01; o[2] = mv.v10; o[3] = mv.v11; break;
     default:
       o[0] = mv.V; o[1] = mv.v00; o[2] = mv.v10; o[3] = mv.v11; o[4] = mv.g;
   }
 }
 
+// INFLX_OP_HESSE: the reference's own v01 (csrc/inflx_sweep_kernels.hip fill_v01)
+static void fill_v01(InflxModelValues& mv, double x0, double x1, const double* p) {
+#if INFLX_V01_IS_V10
+  (void)x0, (void)x1, (void)p;
+  mv.v01 = mv.v10;
+#else
+  mv.v01 = inflx_v01_point(x0, x1, p);
+#endif
+}
+
 extern "C" {
 
+unsigned twin_v01_is_v10() { return INFLX_V01_IS_V10; }
 unsigned twin_n_parameters() { return INFLX_N_PARAMETERS; }
 void twin_set_accuracy(double a) { g_accuracy = a; }
 unsigned twin_out_mask() { return INFLX_OUT_MASK; }
@@ -75,6 +87,7 @@ void twin_grid(int op, const double* p, const double* ss, size_t N0, size_t N1, 
     for (size_t j = 0; j < N1; ++j) {
       InflxModelValues mv;
       inflx_stage_point(x0, inflx_coord(j, dx1, x1a), p, U, R.data(), &C[j * kNC], mv);
+      fill_v01(mv, x0, inflx_coord(j, dx1, x1a), p);
       apply(op, mv, out + (i * N1 + j) * K);
     }
   }
@@ -96,6 +109,7 @@ void twin_trajectory(int op, const double* p, const double* pts, size_t n, doubl
     inflx_stage_col(x1, p, U, C);
     InflxModelValues mv;
     inflx_stage_point(x0, x1, p, U, R, C, mv);
+    fill_v01(mv, x0, x1, p);
     apply(op, mv, out + k * K);
   }
 }

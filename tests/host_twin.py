@@ -39,10 +39,11 @@ class HostTwin:
         self.lib.twin_basis.argtypes = [_DP, _DP, C.c_size_t, _DP]
         self.n_parameters = self.lib.twin_n_parameters()
         self.out_mask = self.lib.twin_out_mask()
+        self.v01_is_v10 = bool(self.lib.twin_v01_is_v10())
 
     @staticmethod
     def _w(op):
-        return {0: 6, 4: 5}.get(op, 1)
+        return {0: 6, 4: 5, 6: 4}.get(op, 1)
 
     def set_accuracy(self, accuracy: float):
         self.lib.twin_set_accuracy(accuracy)

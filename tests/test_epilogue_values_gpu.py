@@ -70,6 +70,18 @@ def _tuples(seed=2024):
     v11 = rng.normal(size=n) * 10.0 ** rng.uniform(-30, 3, size=n)
     g = v * v * 10.0 ** rng.uniform(-5, 40, size=n)
     blocks.append(np.stack([v, v00, v10, v11, g], axis=1))
+    # consistency_only's own denominator |v11/V - 3| + |3 (v00/v10)^2 + (v00/V)(v10/v00)^2| cancelling to exactly zero (0/0 = NaN)
+    # and to next to nothing: v10 = v00 2^k, V = -v00 2^(4k) / 3 makes the second term exactly 0, v11 = 3 V (or an ulp or a
+    # few off) the first one (the quick spelling of inflx_op_consistency_only_quick tests this denominator on its own)
+    n = 60_000
+    k = rng.integers(-6, 7, size=n)
+    mant = rng.integers(1, 2**20, size=n).astype(np.float64)
+    v00 = 3.0 * mant * 2.0 ** rng.integers(-30, 30, size=n) * rng.choice([-1.0, 1.0], size=n)
+    v10 = v00 * 2.0**k
+    v = -(v00 / 3.0) * 2.0 ** (4 * k)
+    v11 = 3.0 * v * (1.0 + rng.integers(-3, 4, size=n) * 2.0**-52 * (rng.random(n) < 0.5))
+    v10 = v10 * (1.0 + rng.integers(-2, 3, size=n) * 2.0**-52 * (rng.random(n) < 0.3))
+    blocks.append(np.stack([v, v00, v10, v11, np.abs(rng.normal(size=n))], axis=1))
     vals = np.concatenate(blocks)
     # the same records once more sorted by t = |v10/v00|: wavefronts whose lanes agree about every branch of atan / tan
     with np.errstate(all="ignore"):

@@ -158,3 +158,67 @@ def test_column_only_model_takes_the_column_broadcast_path(gpu_lib):
     compare(row0[0].cpu().numpy(), om.grid_sweep(oracle.OP.COMPLETE, args, ext, 1, n)[0], 1e-9, "column_only/8192 row 0")
     print(f"column-broadcast sweep 8192^2: {ms:.3f} ms = {48 * n * n / ms / 1e9:.2f} TB/s")
     assert 48 * n * n / (ms * 1e-3) > 4.0e12  # HBM-write-bound like the row path (tile kernels: ~3e12)
+
+
+# ---- the reference's own v01 (Hesse2D loads fns = [v00, v01, v10, v11], hesse_bindings.rs:202-210; `hesse` returns all four) ----
+def _with_a_v01_of_its_own(name="abs_and_sign"):
+    """A model whose v01 is NOT the expression tree of v10: the same function, written differently (expanded), as a
+    symbolic stage leaves it when a simplification succeeds on one component and times out on the other."""
+    import copy
+
+    model, args, ext = _build(name)
+    model = copy.copy(model)
+    h = [list(row) for row in model.hesse_cmp]
+    h[0][1] = sp.expand(h[1][0]) if sp.expand(h[1][0]) != h[1][0] else sp.factor(h[1][0])
+    assert h[0][1] != h[1][0]
+    model.hesse_cmp = h
+    model.model_name = name + "_v01"
+    return model, args, ext
+
+
+def test_v01_is_recognised_as_v10_where_the_trees_are_equal():
+    for name in MODELS:
+        _, _, _, _, comp, hdr, _ = setup(name)
+        assert comp.stage_info["v01_is_v10"] and "#define INFLX_V01_IS_V10 1" in hdr and "inflx_v01_point" not in hdr, name
+
+
+def test_v01_of_its_own_on_the_host_matches_the_oracle():
+    """INFLX_OP_HESSE = [v00, v01, v10, v11]: v01 through the generated `inflx_v01_point` against the oracle's `hesse`
+    (the C function v01 of the reference's emitter, oracle/model_c.py), under the same host compiler with contraction off --
+    the same expression, the same operations: equal to the last few ulps (pow chains), and NOT simply a copy of v10."""
+    model, args, ext = _with_a_v01_of_its_own()
+    comp = Compiler(model, silent=True)
+    hdr = comp._generate_hip_header()
+    assert not comp.stage_info["v01_is_v10"] and "inflx_v01_point" in hdr
+    tw = HostTwin(hdr)
+    assert not tw.v01_is_v10
+    src, _ = oracle.emit_c_source(model)
+    om = oracle.OracleModel(oracle.compile_c_model(src))
+    rng = np.random.default_rng(3)
+    pts = np.column_stack([rng.uniform(ext[0], ext[1], 300), rng.uniform(ext[2], ext[3], 300)])
+    got = tw.trajectory(6, args, pts)
+    want = np.array([om.hesse(x, args).reshape(-1) for x in pts])
+    compare(got, want, 1e-11, "hesse on the host")
+    assert not np.array_equal(want[:, 1], want[:, 2])  # the reference's v01 and v10 differ in their last bits here
+    raw = tw.trajectory(4, args, pts)
+    assert np.array_equal(got[:, [0, 2, 3]], raw[:, 1:4])  # v00, v10, v11 are the staged sweep values, bit for bit
+
+
+@pytest.mark.gpu
+def test_v01_of_its_own_on_the_gpu_matches_the_oracle(gpu_lib):
+    from conftest import generalised_al
+
+    model, args, ext = _with_a_v01_of_its_own()
+    art = Compiler(model, silent=True).compile()
+    al = generalised_al(art)
+    src, _ = oracle.emit_c_source(model)
+    om = oracle.OracleModel(oracle.compile_c_model(src))
+    n0, n1 = 37, 53
+    H = al.calc_H_array(args, ext[0], ext[1], ext[2], ext[3], [n0, n1])
+    assert H.shape == (2, 2, n0, n1) and H.flags.writeable and not np.shares_memory(H[0, 1], H[1, 0])
+    pts = oracle.grid_points(ext, n0, n1)
+    want = np.array([om.hesse(x, args) for x in pts]).reshape(n0, n1, 2, 2).transpose(2, 3, 0, 1)
+    compare(H, want, 1e-12, "calc_H_array with a v01 of its own")
+    assert not np.array_equal(H[0, 1], H[1, 0])
+    x = pts[n1 + 7]
+    compare(al.calc_H(x, args), om.hesse(x, args), 1e-12, "calc_H")

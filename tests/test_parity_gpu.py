@@ -412,10 +412,22 @@ def test_array_helpers(gpu_lib):
     compare(V, raw[..., 0], 1e-10, "calc_V_array")
     H = al.calc_H_array(spec.args, 0.5, 2.5, 0.0, 3.0, [n0, n1])
     assert H.shape == (2, 2, n0, n1)
-    assert not H.flags.writeable and np.shares_memory(H[0, 1], H[1, 0])  # a view of the raw planes, not a 2 GB copy at the default size
-    assert H.copy().flags.writeable and np.array_equal(np.ascontiguousarray(H), H, equal_nan=True)
+    # an ordinary writable array, like the reference documents; H[0, 1] is the reference's own v01, in memory of its own
+    assert H.flags.writeable and H.flags.c_contiguous and not np.shares_memory(H[0, 1], H[1, 0])
+    H *= 1.0  # in-place user code works
     for (a, b), k in (((0, 0), 1), ((1, 0), 2), ((0, 1), 2), ((1, 1), 3)):
         compare(H[a, b], raw[..., k], 1e-9, f"calc_H_array[{a}{b}]")
+    # v01 against the reference's OWN v01 (oracle `hesse`, sweep_oracle.c; both builds of the reference's C): for this model
+    # the expression tree of v01 is that of v10, so the device returns the staged v10 -- the same bits
+    assert art.stage_info["v01_is_v10"] and np.array_equal(H[0, 1], H[1, 0], equal_nan=True)
+    pts = oracle.grid_points((0.5, 2.5, 0.0, 3.0), n0, n1)
+    for cc in COMPILERS:
+        om_cc, _ = oracle_model("doc", cc)
+        v01 = np.array([om_cc.hesse(x, spec.args)[0, 1] for x in pts]).reshape(n0, n1)
+        compare(H[0, 1], v01, 1e-9, f"calc_H_array[01] against the reference's v01 [{cc}]")
+    x = pts[5 * n1 + 3]
+    Hx = al.calc_H(x, spec.args)
+    assert Hx.shape == (2, 2) and np.array_equal(Hx, H[:, :, 5, 3], equal_nan=True)
     # the plane subsets behind the two helpers (inflx_sweep_host_planes: only the requested planes cross PCIe) are the planes of the
     # full planes-layout sweep bit for bit -- every subset, a parameter batch, a row range
     lib = al.dylib

@@ -74,9 +74,9 @@ def test_staged_header_on_host_matches_oracle(name):
         env, flaky = tol.reference_error(name, g["args"], pts)
         env, flaky = env.reshape(n0, n1, 5), flaky.reshape(n0, n1, 5)
         raw = tw.grid(4, g["args"], ext, n0, n1)
-        tol.check(raw, g[f"{tag}_raw"], tol.allowance_raw(g[f"{tag}_raw"], env), flaky, f"{name}/{tag}/raw")
+        tol.check(raw, g[f"{tag}_raw"], tol.allowance_raw(g[f"{tag}_raw"], env), flaky, f"{name}/{tag}/raw", model=name)
         out = tw.grid(0, g["args"], ext, n0, n1)
-        tol.check(out, g[f"{tag}_out"], tol.allowance_derived(g[f"{tag}_raw"], env, tol.epilogue), flaky.any(axis=-1)[..., None], f"{name}/{tag}/out")
+        tol.check(out, g[f"{tag}_out"], tol.allowance_derived(g[f"{tag}_raw"], env, tol.epilogue), flaky.any(axis=-1)[..., None], f"{name}/{tag}/out", model=name)
         if name in ("hyperbolic", "doc"):
             compare(out, g[f"{tag}_out"], 1e-13, f"{name}/{tag}/out strict")
 

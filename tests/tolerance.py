@@ -49,7 +49,9 @@ KAPPA = 64.0  # models not listed
 # numbers to gpurun_out/parity_stats.json; round 2: hyperbolic 3.1 % -- the v11 = -inf row of the 16 x 16 golden
 # grid --, doc 0, angular 0.02 %, EGNO 0, D5 4.95 % on the 16 x 16 golden grid, whose columns hit the singular
 # lines theta = k*pi/2 exactly, 1.2 % on 64 x 48).
-EXCLUDED_CAP_BY_MODEL = {"hyperbolic": 0.08, "doc": 0.01, "angular": 0.005, "egno": 0.002, "d5": 0.10}
+# (round 5: a point where the allowance of a model value exceeds the value itself -- its sign is not settled between the reference's own
+# two builds -- leaves the derived outputs out as well, see allowance_derived: D5 16 x 16, every second column ON a singular line, 9.6 %)
+EXCLUDED_CAP_BY_MODEL = {"hyperbolic": 0.08, "doc": 0.01, "angular": 0.005, "egno": 0.002, "d5": 0.12}
 EXCLUDED_CAP = 0.05
 ULPS = 8.0  # libm-level disagreement granted on the model values themselves, in float64 ulps
 EPS = np.finfo(np.float64).eps
@@ -168,6 +170,12 @@ def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn, model: str | Non
             worst = np.maximum(worst, d)
         # a model value whose own error is unbounded (singular point) leaves the outputs unconstrained
         worst[np.any(~np.isfinite(env), axis=-1)] = np.inf
+        # ... and so does one whose allowance exceeds its own magnitude: the reference does not even settle its SIGN there, the
+        # outputs are not monotonic over a box that contains zero, and its corners say nothing about its interior.  (Found
+        # with the clang-built reference: on D5's lines theta = k pi the gcc build returns v10 = 7e-22 and the clang build
+        # v10 = -v00 = -0.0997 -- E = 0.0997 --; `consistency` is 1.0 for the former, 6e-6 for the latter and ~1 again at
+        # both corners v10 = +-64 E.)
+        worst[np.any(delta > np.abs(ref_raw), axis=-1)] = np.inf
         return RTOL * np.abs(base) + 2.0 * worst
 
 
