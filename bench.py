@@ -44,7 +44,7 @@ FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full r
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
 # parameter-row sweeps (8192^2 each, ~0.45 ms) run untimed before the warm-up steps so that the clocks have settled: 64 = 29 ms
 SETTLE_ROW_SWEEPS = 64
-PROFILE_ROUNDS = ("04", "03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json, rNN_isa_mix.json: newest first
+PROFILE_ROUNDS = ("05", "04", "03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json, rNN_isa_mix.json: newest first
 SIMDS = 256 * 4
 
 
@@ -163,8 +163,7 @@ def issue_weighted(roof, key, code_id, pps):
         return roof
     roof = dict(roof or {"bound": "valu"})
     cyc, clk = rec["weighted_cycles_per_point"], rec.get("clock_GHz")
-    roof["weighted_cycles_per_point"] = cyc
-    roof["dynamic_mix_per_point"] = rec.get("dynamic_mix_per_point")
+    roof["weighted_cycles_per_point"] = cyc  # (the dynamic mix behind it: `dynamic_mix_per_point` of the source file)
     roof["frac_issue_weighted_at_2.4GHz"] = pps * cyc / (SIMDS * 2.4e9)
     if clk:
         roof["shader_clock_GHz_under_this_kernel"] = clk
@@ -255,6 +254,40 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
             torch.cuda.empty_cache()
         except Exception as exc:  # noqa: BLE001 -- an extra must never break the benchmark line
             out.append({"workload": text, "error": str(exc)[:300]})
+    return out
+
+
+def configs_block(secondary):
+    """BASELINE configs[2] / configs[3] (and the doc model) in the compact form that rides INSIDE `roofline` -- the part of the
+    line the driver's record keeps: device time, grid points per second, fraction of the HBM roofline (48 B/point), of the
+    nominal FP64 VALU issue rate (2.4 GHz, one slot per instruction) and of the issue-weighted VALU roofline at the clock the
+    chip holds; default build (the reference's arithmetic) and, beside it, the profile-guided build."""
+    names = {"D5-brane model": "configs[2]", "EGNO supergravity model": "configs[3]", "documentation model (reference tests/test_doc.py)": "doc 4096x4096"}
+    out = {}
+    for rec in secondary:
+        key = names.get(rec.get("workload", "").split(",")[0], rec.get("workload", "?")[:40])
+        if "error" in rec:
+            out[key] = {"error": rec["error"][:120]}
+            continue
+        roof = rec.get("roofline") or {}
+        cell = {"workload": rec["workload"].split(" in ONE call")[0], "kernel": rec["kernel"], "ms": rec["ms"], "points_per_s": rec["points_per_s"], "hbm_frac": rec["hbm_frac"],
+                "valu_frac_nominal": roof.get("frac"), "frac_issue_weighted": roof.get("frac_issue_weighted"), "code_object": rec["code_object"]}
+        pg = rec.get("profile_guided")
+        if pg and "ms" in pg:
+            cell["profile_guided"] = {"ms": pg["ms"], "points_per_s": pg["points_per_s"], "hbm_frac": pg["hbm_frac"],
+                                      "frac_issue_weighted": (pg.get("roofline") or {}).get("frac_issue_weighted"), "code_object": pg["code_object"]}
+        out[key] = cell
+    return out
+
+
+def next_rows_block(rows):
+    """SURVEY section 8(f) rows in compact form, inside `roofline` as well: workload, path, device time, HBM fraction."""
+    out = []
+    for rec in rows:
+        if "error" in rec:
+            out.append({"row": rec.get("row"), "error": rec["error"][:120]})
+        else:
+            out.append({"row": rec["row"], "workload": rec["workload"].split(" (")[0][:70], "path": rec.get("path"), "ms": rec["ms"], "points_per_s": rec["points_per_s"], "hbm_frac": rec.get("hbm_frac")})
     return out
 
 
@@ -637,6 +670,9 @@ def main():
             torch.cuda.empty_cache()
             line["secondary"] = secondary_workloads(_native, workloads, torch, np, local_rank, stream)
             line["next_rows"] = next_rows(_native, workloads, torch, np, local_rank, stream)
+            # the same figures in compact form inside `roofline`, the object the driver's record keeps whole
+            line["roofline"]["configs"] = configs_block(line["secondary"])
+            line["roofline"]["next_rows"] = next_rows_block(line["next_rows"])
             try:
                 line["end_to_end"] = end_to_end(workloads, np, opt.model, opt.n, local_rank)
             except Exception as exc:  # noqa: BLE001

@@ -279,6 +279,25 @@ int inflx_sweep_device_multi(inflx_multi* multi, int op, const double* p, size_t
                              void* const* streams);
 int inflx_sweep_allgather_multi(inflx_multi* multi, int op, const double* p, size_t P, size_t n_p, void* const* d_full,
                                 size_t d_full_bytes, const double* start_stop, size_t N0, size_t N1);
+/*
+ *   inflx_sweep_allgather_multi_ex: the same call with the exchange step chosen by the caller --
+ *     INFLX_GATHER_PEER_PUSH  the direct pushes described above (what inflx_sweep_allgather_multi does; any split, also
+ *                             several handles on one device);
+ *     INFLX_GATHER_RCCL       ONE in-place ncclAllGather over xGMI per contiguous image (the whole array when the parameter
+ *                             axis is split, one per parameter row when grid rows are), all of them fused in one RCCL group
+ *                             and enqueued on every device's sweep stream behind its sweep: the collective BASELINE.json's
+ *                             north_star names ("one RCCL ncclAllGather (equal slabs ...)").  Needs equal
+ *                             blocks (the split axis divides by the device count), one device per handle and a buffer per
+ *                             device; INFLX_ERR_SHAPE / INFLX_ERR_ARG otherwise.  RCCL is bound at run time (the copy already
+ *                             mapped into the process if there is one, e.g. PyTorch's, else librccl.so.1): libinflx_hip.so
+ *                             does not link it, and a caller that never asks for it never loads it.
+ */
+typedef enum inflx_gather {
+  INFLX_GATHER_PEER_PUSH = 0,
+  INFLX_GATHER_RCCL = 1
+} inflx_gather;
+int inflx_sweep_allgather_multi_ex(inflx_multi* multi, int op, const double* p, size_t P, size_t n_p, void* const* d_full,
+                                   size_t d_full_bytes, const double* start_stop, size_t N0, size_t N1, int gather);
 
 #ifdef __cplusplus
 }

@@ -23,6 +23,7 @@ OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
 OP_HESSE = 6  # v00, v01, v10, v11: the projected Hesse matrix with the reference's own v01 (INFLX_SWEEP_HESSE)
 OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5, OP_HESSE: 4}
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
+GATHER_PEER_PUSH, GATHER_RCCL = 0, 1  # inflx_gather: the exchange step of inflx_sweep_allgather_multi_ex
 
 _DP = C.POINTER(C.c_double)
 _SIZE = C.c_size_t
@@ -74,6 +75,7 @@ SIGNATURES = {
     "inflx_sweep_stats_multi": (C.c_int, [C.c_void_p, _DP, _SIZE, _SIZE, _DP, _SIZE, _SIZE, _SIZE, C.c_void_p]),
     "inflx_sweep_device_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.POINTER(C.c_void_p), C.POINTER(_SIZE), _DP, _SIZE, _SIZE, C.c_int, C.POINTER(C.c_void_p)]),
     "inflx_sweep_allgather_multi": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.POINTER(C.c_void_p), _SIZE, _DP, _SIZE, _SIZE]),
+    "inflx_sweep_allgather_multi_ex": (C.c_int, [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.POINTER(C.c_void_p), _SIZE, _DP, _SIZE, _SIZE, C.c_int]),
 }
 
 
@@ -505,14 +507,17 @@ class InflatoxMultiLib:
         st = None if streams is None else (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in streams])
         _check(self._lib.inflx_sweep_device_multi(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, sizes, _ptr(ss), N0, N1, layout, st))
 
-    def sweep_allgather(self, op, p, d_full_ptrs, d_full_bytes, start_stop, N0, N1):
+    def sweep_allgather(self, op, p, d_full_ptrs, d_full_bytes, start_stop, N0, N1, gather="peer_push"):
         """Every ``d_full_ptrs[k]`` (device memory on device k, the whole (P, N0, N1, K) array) holds the whole result on return:
-        each device sweeps its block in place and pushes it to every peer over its own xGMI link (``hipMemcpyPeerAsync``)."""
+        each device sweeps its block in place; ``gather="peer_push"``: it then pushes the block to every peer over its own xGMI
+        link (``hipMemcpyPeerAsync``); ``gather="rccl"``: ONE in-place ``ncclAllGather`` per contiguous image instead (equal
+        blocks, one device per handle)."""
         p2 = _f64(p, "p")
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         ptrs = (C.c_void_p * self.n_devices)(*[C.c_void_p(int(v)) for v in d_full_ptrs])
-        _check(self._lib.inflx_sweep_allgather_multi(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, int(d_full_bytes), _ptr(ss), N0, N1))
+        mode = {"peer_push": GATHER_PEER_PUSH, "rccl": GATHER_RCCL}[gather]
+        _check(self._lib.inflx_sweep_allgather_multi_ex(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, int(d_full_bytes), _ptr(ss), N0, N1, mode))
 
     def sweep_stats(self, p, start_stop, N0, N1, max_devices=0) -> dict:
         p2 = _f64(p, "p")

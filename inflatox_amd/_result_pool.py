@@ -41,16 +41,33 @@ import numpy as np
 def _default_limit() -> int:
     env = os.environ.get("INFLX_RESULT_POOL_MB")
     if env is not None:
-        return max(0, int(env)) << 20
+        try:
+            return max(0, int(env.strip())) << 20
+        except ValueError:  # a malformed value must not break `import inflatox_amd`: fall through to the default
+            pass
     try:
         memory = os.sysconf("SC_PHYS_PAGES") * os.sysconf("SC_PAGE_SIZE")
     except (ValueError, OSError):
         memory = 8 << 30
-    try:  # a container's share of it (cgroup v2)
-        with open("/sys/fs/cgroup/memory.max") as fh:
-            memory = min(memory, int(fh.read().strip()))
-    except (OSError, ValueError):  # no cgroup limit ("max") or no cgroup v2
+    # a container's (or a batch job's) share of it: cgroup v2 `memory.max`, cgroup v1 `memory.limit_in_bytes` (what SLURM's
+    # task/cgroup plugin and older container runtimes set) -- the process's own cgroup first, then the hierarchy root
+    candidates = ["/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"]
+    try:
+        with open("/proc/self/cgroup") as fh:
+            for line in fh:
+                _, controllers, path = line.rstrip("\n").split(":", 2)
+                if controllers == "":  # v2
+                    candidates.insert(0, f"/sys/fs/cgroup{path}/memory.max")
+                elif "memory" in controllers.split(","):  # v1
+                    candidates.insert(0, f"/sys/fs/cgroup/memory{path}/memory.limit_in_bytes")
+    except (OSError, ValueError):
         pass
+    for path in candidates:
+        try:
+            with open(path) as fh:
+                memory = min(memory, int(fh.read().strip()))
+        except (OSError, ValueError):  # no such file, or no limit ("max")
+            pass
     return max(1 << 30, min(memory // 8, 16 << 30))
 
 

@@ -195,6 +195,21 @@ class CompilationArtifact:
         self.auto_cleanup = auto_cleanup
         self.stage_info = stage_info or {}
         self.header_path = header_path
+        self._recipe = None  # (model, Compiler keyword arguments): set by Compiler.compile, used by profile_guided
+
+    def profile_guided(self, args, extent, silent: bool = True) -> "CompilationArtifact":
+        """Extension: the profile-guided build of the same model -- ``Compiler(model, ..., regroup="auto", sample=(args,
+        extent))`` with every other argument as this artefact was compiled with.  ``args`` / ``extent`` are the parameter
+        values and the field range ``(x0_start, x0_stop, x1_start, x1_stop)`` of the intended sweeps: the transpiler
+        MEASURES on them (on the host) which of the five model values may be re-associated within 1e-10 relative plus four times the
+        reference form's own rounding error (Compiler docstring).  The measurement and the code object are cached in-tree,
+        keyed by the model's generated code and the sample.  ``GeneralisedAL(artifact, tuned=True)`` calls this with the
+        arguments of its first sweep."""
+        if self._recipe is None:
+            raise ValueError("this artefact does not know how it was compiled (not made by Compiler.compile)")
+        model, kwargs = self._recipe
+        kwargs = dict(kwargs, regroup="auto", sample=(args, extent), silent=silent, tan_shortcut=None)
+        return Compiler(model, **kwargs).compile()
 
     def __del__(self):
         if getattr(self, "auto_cleanup", False):
@@ -379,6 +394,9 @@ class Compiler:
         sample=None,
         quick_sqrt: bool | None = None,
     ):
+        # what CompilationArtifact.profile_guided needs to compile the same model again with a measured re-association
+        self._init_kwargs = dict(output_path=None, cleanup=cleanup, silent=silent, link_gsl=link_gsl, cse=cse, max_cses=max_cses, compiler_flags=compiler_flags,
+                                 staged=staged, exact_constants=exact_constants, hoist_reciprocals=hoist_reciprocals, share_reciprocals=share_reciprocals, quick_sqrt=quick_sqrt)
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
         self.gsl = bool(link_gsl)
@@ -671,7 +689,7 @@ class Compiler:
         fd, out_path = tempfile.mkstemp(prefix=self.lib_prefix, suffix=".hsaco")
         os.close(fd)
         shutil.copyfile(cached, out_path)
-        return CompilationArtifact(
+        art = CompilationArtifact(
             self.symbol_dict,
             out_path,
             self.symbolic_out.dim,
@@ -680,3 +698,5 @@ class Compiler:
             stage_info=self.stage_info,
             header_path=header_path,
         )
+        art._recipe = (self.symbolic_out, dict(self._init_kwargs))
+        return art

@@ -10,6 +10,7 @@
 // fails with INFLX_ERR_DEVICE.
 #include "inflx_hip.h"
 
+#include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -610,6 +611,13 @@ size_t tile_height(size_t full, size_t segments) {
   return std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
 }
 
+// Vertically consecutive tiles per workgroup of a launch of `tiles` full- or part-height tiles: 1 until the measurement says otherwise
+// (scripts/tiles_per_wg_probe.py).
+size_t tiles_per_workgroup(size_t tiles, bool full_height) {
+  (void)tiles, (void)full_height;
+  return 1;
+}
+
 int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
                  double* d_stats) {
   void* params[] = {&a};
@@ -665,7 +673,16 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
         if (rows > 0) th = std::min<size_t>(full, (size_t)rows);
       }
       a.tile_rows = (uint32_t)th;
-      const size_t gy = (slab + th - 1) / th;
+      // tiles one workgroup walks one after the other (kernel: `tiles_per_wg`).  Experiments: INFLX_EXPERIMENT_TILES_PER_WG.
+      size_t per_wg = tiles_per_workgroup(gx * ((slab + th - 1) / th) * pb, th == full);
+      static const bool forced_tiles = getenv("INFLX_EXPERIMENT_TILES_PER_WG") != nullptr;
+      if (forced_tiles) {
+        const char* e = getenv("INFLX_EXPERIMENT_TILES_PER_WG");
+        const int n = e ? atoi(e) : 0;
+        if (n > 0) per_wg = (size_t)n;
+      }
+      a.reserved0 = (uint32_t)per_wg;
+      const size_t gy = ((slab + th - 1) / th + per_wg - 1) / per_wg;
       HIP_TRY(probe_begin(m, s));
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
       HIP_TRY(probe_end(m, s));
@@ -1496,7 +1513,9 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     if ((m->info.out_mask & 2u) == 0 && N1 > 1) return sweep_host_broadcast(m, op, 1, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
     if ((m->info.out_mask & 3u) == 2u && row_count > 1) return sweep_host_broadcast(m, op, 0, p, P, n_p, out, ss, N0, N1, row_begin, row_count, layout, dest, progress);
   }
-  bool whole = total <= whole_result_limit() || subset;  // (a plane subset is copied out of the whole result: no chunk pipeline for it)
+  // (a plane subset prefers the whole-result path whatever its size -- one launch, few large copies -- and falls back to the chunk
+  // pipeline like everything else when that much HBM is not free)
+  bool whole = whole_result_limit() != 0 && (total <= whole_result_limit() || subset);  // (INFLX_WHOLE_RESULT_MB=0 switches the path off altogether)
   if (whole && total > m->d_whole_cap) {
     if (m->d_whole) HIP_TRY(hipFree(m->d_whole));
     m->d_whole = nullptr;
@@ -1506,8 +1525,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     } else {
       (void)hipGetLastError();  // not enough free HBM for the whole result: the chunk pipeline needs 64 MiB
       m->d_whole = nullptr;
-      whole = false;
-      if (subset) return fail(INFLX_ERR_DEVICE, "not enough free device memory for the %zu-byte result a plane subset is copied from", total);
+      whole = false;  // (a plane subset too: the pipeline below copies the requested planes of every chunk)
     }
   }
   // the stream of the kernels that read the parameters: decided by the P the launches below really see (the
@@ -1604,8 +1622,9 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     }
     if (progress && e == hipSuccess) progress->done += unmarked;
     for (auto& th : pool) th.join();
-    // a buffer of many GiB is not kept between calls (the model would sit on that much HBM)
-    if (m->d_whole_cap > (size_t(4) << 30)) {
+    // a buffer of many GiB is not kept between calls (the model would sit on that much HBM); after a plane subset -- calc_V_array
+    // keeps one plane of five -- not even one of more than 1 GiB
+    if (m->d_whole_cap > (size_t(4) << 30) || (subset && m->d_whole_cap > (size_t(1) << 30))) {
       (void)hipFree(m->d_whole);
       m->d_whole = nullptr;
       m->d_whole_cap = 0;
@@ -1628,16 +1647,19 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   for (size_t pr = 0; pr < P; ++pr)
     for (size_t r = 0; r < row_count; r += rows_per_chunk) pieces.push_back({pr, r, std::min(rows_per_chunk, row_count - r)});
   const bool planes = layout == INFLX_SOA && K > 1;
+  // planes [k_lo, k_hi) of every chunk reach the host; the destination holds k_hi - k_lo planes per parameter row (all K unless a subset was asked for)
+  const size_t k_lo = subset ? dest.plane0 : 0, k_hi = subset ? dest.plane0 + dest.planes : K;
+  const size_t piece_row_bytes = planes ? (k_hi - k_lo) * N1 * sizeof(double) : row_bytes;  // host bytes per grid row of a piece (progress)
   // where rows [r, r + nrows) of parameter row pr (plane k) land in the caller's array
   auto dst_of = [&](const Piece& pc, size_t k) {
-    return planes ? out + (((pc.pr * K + k) * dest.dst_rows) + dest.dst_row0 + pc.r) * N1 * sizeof(double)
+    return planes ? out + (((pc.pr * (k_hi - k_lo) + (k - k_lo)) * dest.dst_rows) + dest.dst_row0 + pc.r) * N1 * sizeof(double)
                   : out + ((pc.pr * dest.dst_rows) + dest.dst_row0 + pc.r) * row_bytes;
   };
   auto touch = [&](const Piece& pc) {
     if (!planes) {
       prefault_range(dst_of(pc, 0), pc.nrows * row_bytes);
     } else {
-      for (size_t k = 0; k < K; ++k) prefault_range(dst_of(pc, k), pc.nrows * N1 * sizeof(double));
+      for (size_t k = k_lo; k < k_hi; ++k) prefault_range(dst_of(pc, k), pc.nrows * N1 * sizeof(double));
     }
   };
   auto start_touch = [&](const Piece& pc) {
@@ -1668,7 +1690,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       hipError_t we = progress ? hipEventSynchronize(m->copy_done[b]) : hipStreamWaitEvent(m->stream, m->copy_done[b], 0);
       if (we != hipSuccess) { drain(); return fail(INFLX_ERR_DEVICE, "waiting for a chunk copy failed: %s", hipGetErrorString(we)); }
       if (progress)
-        for (; counted + 2 <= c; ++counted) progress->done += pieces[counted].nrows * row_bytes;
+        for (; counted + 2 <= c; ++counted) progress->done += pieces[counted].nrows * piece_row_bytes;
     }
     rc = launch_grid(m, op, d_params + pc.pr * n_p, 1, static_cast<double*>(m->d_chunk[b]), ss, N0, N1, row_begin + pc.r, pc.nrows, layout,
                      m->stream, 0, accuracy);
@@ -1681,7 +1703,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
       if (!planes) {
         e = hipMemcpyAsync(dst_of(pc, 0), m->d_chunk[b], pc.nrows * row_bytes, hipMemcpyDeviceToHost, m->copy_stream);
       } else {
-        for (size_t k = 0; k < K && e == hipSuccess; ++k) {
+        for (size_t k = k_lo; k < k_hi && e == hipSuccess; ++k) {
           const double* src = static_cast<const double*>(m->d_chunk[b]) + k * pc.nrows * N1;
           e = hipMemcpyAsync(dst_of(pc, k), src, pc.nrows * N1 * sizeof(double), hipMemcpyDeviceToHost, m->copy_stream);
         }
@@ -1695,7 +1717,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   HIP_TRY(hipStreamSynchronize(m->copy_stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
   if (progress)
-    for (; counted < pieces.size(); ++counted) progress->done += pieces[counted].nrows * row_bytes;
+    for (; counted < pieces.size(); ++counted) progress->done += pieces[counted].nrows * piece_row_bytes;
   return INFLX_OK;
 }
 
@@ -1830,10 +1852,73 @@ struct inflx_multi {
   // the pushes behind the sweep
   std::vector<std::vector<hipStream_t>> push;  // push[k][j]: stream on device k that copies towards device j
   std::vector<hipEvent_t> swept;               // recorded on device k's sweep stream behind its sweep
+  // the same gather as ONE RCCL collective (inflx_sweep_allgather_multi_ex, INFLX_GATHER_RCCL): one communicator per device,
+  // created by ncclCommInitAll on first use (void*: RCCL is loaded at run time, see rccl_api())
+  std::vector<void*> comms;
   std::mutex mu;
 };
 
 namespace {
+// RCCL, bound at run time.  The library is not a link-time dependency of libinflx_hip.so: the single-GPU product needs no
+// collective at all, and a process that has PyTorch loaded already holds a copy of RCCL (torch bundles one) -- a second copy
+// pulled in by the dynamic linker would be a second set of communicator state.  So: the copy that is already mapped if
+// there is one, else the system's.
+struct RcclApi {
+  int (*CommInitAll)(void** comms, int ndev, const int* devlist) = nullptr;
+  int (*CommDestroy)(void* comm) = nullptr;
+  int (*AllGather)(const void* send, void* recv, size_t count, int dtype, void* comm, hipStream_t stream) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+  std::string origin;
+};
+constexpr int kNcclFloat64 = 8;  // ncclDataType_t::ncclFloat64 (rccl.h)
+
+const RcclApi* rccl_api() {
+  static const RcclApi api = [] {
+    RcclApi a;
+    void* h = nullptr;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    for (const char* nm : names)
+      if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) { a.origin = std::string(nm) + " (already mapped)"; break; }
+    if (!h)
+      for (const char* nm : names)
+        if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) { a.origin = nm; break; }
+    if (!h) return a;
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    return a;
+  }();
+  return (api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString) ? &api : nullptr;
+}
+
+#define RCCL_TRY(api, expr)                                                                                       \
+  do {                                                                                                            \
+    const int r_ = (expr);                                                                                        \
+    if (r_ != 0) return fail(INFLX_ERR_DEVICE, "%s failed: %s", #expr, (api)->GetErrorString(r_));               \
+  } while (0)
+
+int ensure_comms(inflx_multi* mm, const RcclApi* api) {
+  std::lock_guard<std::mutex> g(mm->mu);
+  const size_t n = mm->dev.size();
+  if (mm->comms.size() == n) return INFLX_OK;
+  std::vector<int> devs(n);
+  for (size_t k = 0; k < n; ++k) devs[k] = mm->dev[k]->device;
+  for (size_t k = 0; k < n; ++k)
+    for (size_t j = k + 1; j < n; ++j)
+      if (devs[k] == devs[j])
+        return fail(INFLX_ERR_ARG, "the RCCL all-gather needs one device per handle (device %d appears twice): a communicator has one rank per GPU; "
+                    "the peer-push gather (INFLX_GATHER_PEER_PUSH) has no such restriction", devs[k]);
+  std::vector<void*> comms(n, nullptr);
+  RCCL_TRY(api, api->CommInitAll(comms.data(), (int)n, devs.data()));
+  mm->comms = std::move(comms);
+  return INFLX_OK;
+}
+
 // Run `part(k)` for k in [0, n) -- one host thread per part, part 0 on the calling thread -- and report the first failure
 // (status and message) on the calling thread.
 template <typename F>
@@ -2010,6 +2095,14 @@ void inflx_close_multi(inflx_multi* mm) {
       }
     if (k < mm->swept.size() && mm->swept[k]) (void)hipEventDestroy(mm->swept[k]);
   }
+  if (!mm->comms.empty()) {
+    if (const RcclApi* api = rccl_api())
+      for (size_t k = 0; k < mm->comms.size(); ++k)
+        if (mm->comms[k]) {
+          (void)hipSetDevice(mm->dev[k]->device);
+          (void)api->CommDestroy(mm->comms[k]);
+        }
+  }
   for (inflx_model* m : mm->dev) inflx_close(m);
   delete mm;
 }
@@ -2111,24 +2204,44 @@ int ensure_push_streams(inflx_multi* mm) {
   std::lock_guard<std::mutex> g(mm->mu);
   const size_t n = mm->dev.size();
   if (mm->push.size() == n) return INFLX_OK;
-  mm->push.assign(n, std::vector<hipStream_t>(n, nullptr));
-  mm->swept.assign(n, nullptr);
-  for (size_t k = 0; k < n; ++k) {
-    HIP_TRY(hipSetDevice(mm->dev[k]->device));
-    HIP_TRY(hipEventCreateWithFlags(&mm->swept[k], hipEventDisableTiming));
+  // built aside and published only when every stream and event exists: a failure part-way must not leave a table of the right
+  // size with null entries behind (the next call would take it for complete and record / copy on null handles)
+  std::vector<std::vector<hipStream_t>> push(n, std::vector<hipStream_t>(n, nullptr));
+  std::vector<hipEvent_t> swept(n, nullptr);
+  hipError_t e = hipSuccess;
+  const char* what = "";
+  for (size_t k = 0; k < n && e == hipSuccess; ++k) {
+    if ((e = hipSetDevice(mm->dev[k]->device)) != hipSuccess) { what = "hipSetDevice"; break; }
+    if ((e = hipEventCreateWithFlags(&swept[k], hipEventDisableTiming)) != hipSuccess) { what = "hipEventCreateWithFlags"; break; }
     for (size_t j = 0; j < n; ++j) {
       if (j == k) continue;
-      HIP_TRY(hipStreamCreateWithFlags(&mm->push[k][j], hipStreamNonBlocking));
+      if ((e = hipStreamCreateWithFlags(&push[k][j], hipStreamNonBlocking)) != hipSuccess) { what = "hipStreamCreateWithFlags"; break; }
       const int a = mm->dev[k]->device, b = mm->dev[j]->device;
       if (a != b) {
         int can = 0;
         if (hipDeviceCanAccessPeer(&can, a, b) == hipSuccess && can) {
-          (void)hipDeviceEnablePeerAccess(b, 0);  // "already enabled" is fine; without it the runtime stages the copy
+          const hipError_t pe = hipDeviceEnablePeerAccess(b, 0);  // "already enabled" is fine
           (void)hipGetLastError();
+          if (pe != hipSuccess && pe != hipErrorPeerAccessAlreadyEnabled)
+            warn("peer access from device %d to device %d could not be enabled (%s): the all-gather stages these copies through the host", a, b, hipGetErrorString(pe));
+        } else {
+          (void)hipGetLastError();
+          warn("device %d cannot access device %d directly: the all-gather stages these copies through the host", a, b);
         }
       }
     }
   }
+  if (e != hipSuccess) {
+    for (size_t k = 0; k < n; ++k) {
+      (void)hipSetDevice(mm->dev[k]->device);
+      if (swept[k]) (void)hipEventDestroy(swept[k]);
+      for (hipStream_t st : push[k])
+        if (st) (void)hipStreamDestroy(st);
+    }
+    return fail(INFLX_ERR_DEVICE, "%s failed while preparing the peer copies: %s", what, hipGetErrorString(e));
+  }
+  mm->push = std::move(push);
+  mm->swept = std::move(swept);
   return INFLX_OK;
 }
 }  // namespace
@@ -2153,7 +2266,13 @@ int inflx_sweep_device_multi(inflx_multi* mm, int op, const double* p, size_t P,
 
 int inflx_sweep_allgather_multi(inflx_multi* mm, int op, const double* p, size_t P, size_t n_p, void* const* d_full, size_t d_full_bytes,
                                 const double* ss, size_t N0, size_t N1) {
+  return inflx_sweep_allgather_multi_ex(mm, op, p, P, n_p, d_full, d_full_bytes, ss, N0, N1, INFLX_GATHER_PEER_PUSH);
+}
+
+int inflx_sweep_allgather_multi_ex(inflx_multi* mm, int op, const double* p, size_t P, size_t n_p, void* const* d_full, size_t d_full_bytes,
+                                   const double* ss, size_t N0, size_t N1, int gather) {
   if (!mm || mm->dev.empty()) return fail(INFLX_ERR_ARG, "multi-device handle is NULL or empty");
+  if (gather != INFLX_GATHER_PEER_PUSH && gather != INFLX_GATHER_RCCL) return fail(INFLX_ERR_ARG, "unknown gather %d", gather);
   if (!d_full) return fail(INFLX_ERR_ARG, "device buffer array is NULL");
   if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif on one device");
   int rc = validate(mm->dev[0], op, p, P, n_p);
@@ -2162,7 +2281,22 @@ int inflx_sweep_allgather_multi(inflx_multi* mm, int op, const double* p, size_t
   const size_t point_bytes = kOpBytes[op];
   if (d_full_bytes < P * N0 * N1 * point_bytes) return fail(INFLX_ERR_SHAPE, "every full-size buffer needs %zu bytes (got %zu)", P * N0 * N1 * point_bytes, d_full_bytes);
   if (N0 == 0 || N1 == 0) return INFLX_OK;
-  if ((rc = ensure_push_streams(mm))) return rc;
+  const RcclApi* api = nullptr;
+  if (gather == INFLX_GATHER_RCCL) {
+    // ncclAllGather moves equal counts: the split axis must divide by the number of devices (shard_plan then gives every device
+    // the same block), and every device a buffer of its own
+    const ShardPlan s0 = shard_plan(P, N0, world, 0);
+    if ((s0.axis == 0 ? P : N0) % world != 0)
+      return fail(INFLX_ERR_SHAPE, "the RCCL all-gather needs equal blocks: %zu %s do not divide by %zu devices (the peer-push gather takes unequal ones)",
+                  s0.axis == 0 ? P : N0, s0.axis == 0 ? "parameter rows" : "grid rows", world);
+    for (size_t k = 0; k < world; ++k)
+      for (size_t j = k + 1; j < world; ++j)
+        if (d_full[k] == d_full[j]) return fail(INFLX_ERR_ARG, "the RCCL all-gather needs a buffer per device (buffers %zu and %zu are the same)", k, j);
+    if (!(api = rccl_api())) return fail(INFLX_ERR_DEVICE, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if ((rc = ensure_comms(mm, api))) return rc;
+  } else if ((rc = ensure_push_streams(mm))) {
+    return rc;
+  }
   // AOS only: a device's slab is then one contiguous piece per parameter row of the (P, N0, N1, K) array
   const size_t row_bytes = N1 * point_bytes;
   for (size_t k = 0; k < world; ++k) {
@@ -2184,6 +2318,7 @@ int inflx_sweep_allgather_multi(inflx_multi* mm, int op, const double* p, size_t
         if (rc) return rc;
       }
     }
+    if (gather == INFLX_GATHER_RCCL) continue;  // the collective below runs on every device's sweep stream, behind its sweep
     HIP_TRY(hipEventRecord(mm->swept[k], m->stream));
     for (size_t j = 0; j < world; ++j) {
       if (j == k || d_full[j] == d_full[k]) continue;
@@ -2198,13 +2333,34 @@ int inflx_sweep_allgather_multi(inflx_multi* mm, int op, const double* p, size_t
       }
     }
   }
+  if (gather == INFLX_GATHER_RCCL) {
+    // In place (rccl.h: sendbuff == recvbuff + rank * sendcount): the device's own block is where the sweep put it.  Split along
+    // the parameter axis the whole (P, N0, N1, K) array is ONE gather; split along grid rows every parameter row is one (its
+    // blocks are contiguous within the row's (N0, N1, K) image) -- all of them, for all devices, fused in one group.
+    const ShardPlan s0 = shard_plan(P, N0, world, 0);
+    const size_t gathers = s0.axis == 0 ? 1 : P;
+    const size_t block_bytes = s0.axis == 0 ? s0.p_count * N0 * row_bytes : s0.row_count * row_bytes;
+    const size_t image_bytes = s0.axis == 0 ? P * N0 * row_bytes : N0 * row_bytes;
+    RCCL_TRY(api, api->GroupStart());
+    for (size_t q = 0; q < gathers; ++q)
+      for (size_t k = 0; k < world; ++k) {
+        char* base = static_cast<char*>(d_full[k]) + q * image_bytes;
+        const int r = api->AllGather(base + k * block_bytes, base, block_bytes / sizeof(double), kNcclFloat64, mm->comms[k], mm->dev[k]->stream);
+        if (r != 0) {
+          (void)api->GroupEnd();
+          return fail(INFLX_ERR_DEVICE, "ncclAllGather failed: %s", api->GetErrorString(r));
+        }
+      }
+    RCCL_TRY(api, api->GroupEnd());
+  }
   // synchronous: every device holds the whole result when the call returns
   for (size_t k = 0; k < world; ++k) {
     HIP_TRY(hipSetDevice(mm->dev[k]->device));
     HIP_TRY(hipStreamSynchronize(mm->dev[k]->side));
     HIP_TRY(hipStreamSynchronize(mm->dev[k]->stream));
-    for (size_t j = 0; j < world; ++j)
-      if (mm->push[k][j]) HIP_TRY(hipStreamSynchronize(mm->push[k][j]));
+    if (gather == INFLX_GATHER_PEER_PUSH)
+      for (size_t j = 0; j < world; ++j)
+        if (mm->push[k][j]) HIP_TRY(hipStreamSynchronize(mm->push[k][j]));
   }
   return INFLX_OK;
 }

@@ -346,9 +346,14 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const double x1 = inflx_coord(j, a.dx1, a.x1a);
   // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
   const unsigned tile_rows = a.tile_rows;  // height of this launch's tiles (<= kTileRows; lower for small grids)
-  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * tile_rows;
-  const uint64_t left = a.row_count - row0;
-  const int nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
+  // A workgroup walks `tiles_per_wg` vertically consecutive tiles of its 256 columns (same parameter row): its column values, its
+  // parameter-only values and the epilogue's coefficients are loaded once, only the 32 rows of R values are restaged per tile --
+  // and the wave slots it holds stay filled across what would otherwise be that many workgroup hand-overs (round 5: SQ_WAVE_CYCLES
+  // puts D5's mean occupancy at 2.64 of 3 wavefronts per SIMD while the SPI never has a workgroup waiting that does not fit).
+  const unsigned tiles_per_wg = a.reserved0 ? a.reserved0 : 1u;
+  uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * tiles_per_wg * tile_rows;
+  uint64_t left = a.row_count - row0;
+  int nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
 #ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE  // (A/B experiment only: the round-1 prologue, every workgroup evaluates its own stage values)
 #if INFLX_U_IN_LDS
   __shared__ __attribute__((aligned(16))) double U[kNU];
@@ -378,7 +383,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #pragma unroll
   for (int k = 0; k < kNC; ++k) C[k] = j < a.N1 ? ctab[(uint64_t)k * a.N1 + j] : 0.0;
   {
-    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * tile_rows * kNRs;
+    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * tiles_per_wg * tile_rows * kNRs;
     double* dst = &Rs[0][0];
     for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
   }
@@ -476,6 +481,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   // 4096 columns); after two consecutive irregular rows it therefore stops trying and leaves the remaining rows
   // to the IEEE loop directly.
   static_assert(kTileRows <= 64, "one bit per tile row");
+  for (unsigned tile = 0;; ++tile) {
   uint64_t redo = 0;
   int streak = 0;  // consecutive irregular rows (wave-uniform)
   for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
@@ -520,6 +526,27 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     double o[K];
     apply_op<OP, kTable>(mv, o, a.accuracy, kc);
     emit(o, row);
+  }
+  // the next tile of this workgroup: its rows of R values replace this tile's once every wavefront is done reading them
+  if (tile + 1 >= tiles_per_wg) break;
+  row0 += tile_rows;
+  if (row0 >= (uint64_t)a.stream_row0 + a.stream_units || row0 >= a.row_count) break;  // (workgroup-uniform)
+  left = a.row_count - row0;
+  nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
+  __syncthreads();
+  {
+#ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE
+    if ((int)tid < nrows) inflx_stage_row(inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a), A, U, Rs[tid]);
+#else
+    const double* __restrict__ src = rtab + (row0 - a.stream_row0) * kNRs;
+    double* dst = &Rs[0][0];
+    for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
+#endif
+  }
+  __syncthreads();
+#if INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP
+  __builtin_amdgcn_s_waitcnt(0x0F70);  // (see above: the row loop must not wait on this tile's table loads behind its stores)
+#endif
   }
   if constexpr (STATS) stat_flush(acc, a.stats);
 }

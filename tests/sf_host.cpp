@@ -12,6 +12,7 @@ using std::tgamma;
 using std::tan;
 using std::log1p;
 using std::sinh;
+using std::tanh;
 using std::cosh;
 using std::log;
 using std::sin;

@@ -45,6 +45,13 @@ def test_single_gpu_line():
     assert all("error" not in rec for rec in line["secondary"]), line["secondary"]
     assert sec["D5-brane model"]["points_per_s"] > 1e9 and sec["EGNO supergravity model"]["points_per_s"] > 1e9
     assert "x 32 parameter rows" in sec["D5-brane model"]["workload"]
+    # ... and, compact, inside `roofline` -- the object the driver's record keeps whole
+    cfg = roof["configs"]
+    assert set(cfg) == {"configs[2]", "configs[3]", "doc 4096x4096"}
+    assert abs(cfg["configs[2]"]["ms"] - sec["D5-brane model"]["ms"]) < 1e-12 and abs(cfg["configs[3]"]["points_per_s"] - sec["EGNO supergravity model"]["points_per_s"]) < 1e-3
+    assert all(0 < c["hbm_frac"] < 1 and len(c["code_object"]) == 20 and c["profile_guided"]["ms"] > 0 for c in cfg.values())
+    assert len(json.dumps(roof)) < 7000  # stays inside the driver's record
+    assert len(roof["next_rows"]) == len(line["next_rows"])
     assert line["end_to_end"]["points_per_s"] > 1e8
     # the single-quantity sweeps, an on-trajectory call and the raw-values planes are measured on the same line
     rows = line["next_rows"]

@@ -116,6 +116,36 @@ print("chunked ok")
 """
 
 
+_SUBSET = """
+import sys
+sys.path.insert(0, {root!r})
+import numpy as np
+from inflatox_amd import _native
+import workloads
+spec, art = workloads.artifact_for("doc")
+lib = _native.InflatoxDevLib(art.shared_object_path)
+rows = np.stack([spec.args, spec.args * 1.25, spec.args * 0.8])
+ext = (0.5, 2.5, 0.0, 3.0)
+full = lib.sweep_host(_native.OP_RAW, rows, ext, 300, 520, row_begin=7, row_count=250, layout=_native.LAYOUT_SOA)
+for first, count in ((0, 1), (1, 3), (4, 1), (0, 5), (2, 2)):
+    part = lib.sweep_host_planes(_native.OP_RAW, rows, ext, 300, 520, first, count, row_begin=7, row_count=250)
+    assert part.shape == (3, count, 250, 520) and np.array_equal(part, full[:, first:first + count], equal_nan=True), (first, count)
+hess = lib.sweep_host(_native.OP_HESSE, rows[0], ext, 300, 520, row_begin=7, row_count=250, layout=_native.LAYOUT_SOA)  # v00, v01, v10, v11
+assert hess.shape == (4, 250, 520) and np.array_equal(hess[[0, 2, 3]], full[0, 1:4], equal_nan=True)
+print("subset ok")
+"""
+
+
+@pytest.mark.gpu
+def test_plane_subsets_through_the_chunk_pipeline(gpu_lib):
+    """A plane subset (calc_V_array: one plane of five) prefers the whole-result path and falls back to the chunk pipeline when
+    that much HBM is not free -- forced here by switching the whole-result path off (INFLX_WHOLE_RESULT_MB=0) with 1 MiB chunks:
+    every subset of a parameter batch and a row range equals the planes of the full planes-layout sweep bit for bit."""
+    env = dict(os.environ, INFLX_WHOLE_RESULT_MB="0", INFLX_CHUNK_MB="1")
+    proc = subprocess.run([sys.executable, "-c", _SUBSET.format(root=ROOT)], env=env, capture_output=True, text=True, timeout=600)
+    assert proc.returncode == 0 and "subset ok" in proc.stdout, proc.stdout + proc.stderr
+
+
 @pytest.mark.gpu
 def test_chunk_pipeline_and_progress_lines_of_a_multi_device_sweep(gpu_lib):
     """The same comparison through the chunk pipeline (results larger than the whole-result limit: forced with
@@ -171,6 +201,41 @@ def test_device_resident_multi_sweep_and_peer_all_gather(name, gpu_lib):
                     assert np.array_equal(b.cpu().numpy(), ref, equal_nan=True), (devices, P, n0, n1, pl)
         with pytest.raises(gpu_lib.InflatoxShapeError):
             multi.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:2], [t.data_ptr() for t in full], 8, spec.extent, 8, 8)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_all_gather_through_rccl(name, gpu_lib):
+    """inflx_sweep_allgather_multi_ex(..., INFLX_GATHER_RCCL): the exchange step as ONE in-place ncclAllGather per contiguous image
+    (SURVEY section 8e).  A one-GPU box has one rank to offer (RCCL refuses two ranks on a device): the communicator is created
+    by ncclCommInitAll, the collective is enqueued on the sweep stream behind the sweep and the result equals the host sweep --
+    parameter-axis and row-axis plans, every operation width; the argument checks (unequal blocks, one device twice) answer
+    with the documented errors instead of reaching RCCL."""
+    import torch
+
+    import workloads
+
+    spec, art = workloads.artifact_for(name)
+    one = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    rng = np.random.default_rng(12)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.8, 1.25, size=(4, len(spec.args)))
+    multi = gpu_lib.InflatoxMultiLib(art.shared_object_path, [0])
+    for op, width in ((gpu_lib.OP_COMPLETE, 6), (gpu_lib.OP_RAW, 5), (gpu_lib.OP_EPSILON_V, 1)):
+        for P, n0, n1 in ((3, 36, 130), (1, 64, 96)):
+            want = one.sweep_host(op, rows[:P], spec.extent, n0, n1).reshape(P, n0, n1, width)
+            full = torch.full((P, n0, n1, width), -5.0, dtype=torch.float64, device="cuda:0")
+            torch.cuda.synchronize()
+            multi.sweep_allgather(op, rows[:P], [full.data_ptr()], full.numel() * 8, spec.extent, n0, n1, gather="rccl")
+            assert np.array_equal(full.cpu().numpy(), want, equal_nan=True), (op, P, n0, n1)
+    # two handles on the one device: the peer-push gather takes them, the RCCL one says why it cannot
+    two = gpu_lib.InflatoxMultiLib(art.shared_object_path, [0, 0])
+    bufs = [torch.empty((2, 8, 8, 6), dtype=torch.float64, device="cuda:0") for _ in range(2)]
+    with pytest.raises(ValueError, match="one device per handle"):
+        two.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:2], [b.data_ptr() for b in bufs], bufs[0].numel() * 8, spec.extent, 8, 8, gather="rccl")
+    with pytest.raises(gpu_lib.InflatoxShapeError, match="equal blocks"):
+        two.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:3], [b.data_ptr() for b in bufs], 3 * 8 * 8 * 48, spec.extent, 8, 8, gather="rccl")
+    two.sweep_allgather(gpu_lib.OP_COMPLETE, rows[:2], [b.data_ptr() for b in bufs], bufs[0].numel() * 8, spec.extent, 8, 8)  # peer pushes
+    assert np.array_equal(bufs[0].cpu().numpy(), bufs[1].cpu().numpy(), equal_nan=True)
 
 
 def test_parameter_grid_is_the_outer_product_of_its_axes():

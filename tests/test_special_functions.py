@@ -267,6 +267,25 @@ def test_real_order_bessel_functions_on_host_against_mpmath(sf, kind):
         assert z[0] == want
 
 
+def test_real_order_bessel_functions_at_tiny_arguments(sf):
+    """x below 1e-152: the steepest-descent nodes reach |u| > 355 where sinh(u)^2 overflows (the integrand's tanh and sech are
+    taken by name, not from sqrt(1 + sinh^2)): Y_0(1e-160) = -234.5..., Y_{1/2}(1e-200) = -8e99, J_0 = 1, finite wherever the
+    true value is."""
+    import mpmath as mp
+
+    cases = [("Ynu", 0.0, 1e-160), ("Ynu", 0.0, 1e-250), ("Ynu", 0.5, 1e-200), ("Ynu", 0.25, 1e-300), ("Jnu", 0.0, 1e-200), ("Jnu", 0.5, 1e-160), ("Ynu", 1.5, 1e-160)]
+    fn = {"Jnu": mp.besselj, "Ynu": mp.bessely}
+    with mp.workdps(40):
+        for name, nu, x in cases:
+            out = np.zeros(1)
+            getattr(sf, f"sf_{name}")(C.c_double(nu), np.array([x]).ctypes.data_as(DP), 1, out.ctypes.data_as(DP))
+            want = fn[name](nu, mp.mpf(x))
+            if abs(want) > 1e300:
+                assert out[0] == -np.inf or abs(out[0]) > 1e300, (name, nu, x, out[0])
+                continue
+            assert np.isfinite(out[0]) and abs(out[0] - float(want)) <= 1e-13 * abs(float(want)), (name, nu, x, out[0], float(want))
+
+
 def test_real_order_bessel_model_on_host_twin_against_mpmath():
     """A model with Bessel functions of real order (a half-integer number and a model parameter; all four kinds): the
     printer emits inflx_sf_bessel_*nu where the reference emits gsl_sf_bessel_*nu, orders shifted by differentiation

@@ -365,3 +365,19 @@ def test_profile_guided_regrouping_measures_which_values_qualify(name):
     tol.check(x, g["g64_raw"], tol.allowance_raw(g["g64_raw"], env, name), flaky, f"{name}/g64/raw (regroup=auto)", model=name)
     with pytest.raises(ValueError, match="sample"):
         Compiler(workloads.model_for(name), silent=True, regroup="auto")
+
+
+def test_an_artefact_can_rebuild_itself_profile_guided():
+    """``CompilationArtifact.profile_guided(args, extent)`` = ``Compiler(model, <same arguments>, regroup="auto", sample=...)``:
+    the code object workloads.artifact_for(name, tuned=True) builds by hand, found in the cache by its content tag."""
+    import workloads
+
+    spec, art = workloads.artifact_for("doc")
+    _, by_hand = workloads.artifact_for("doc", tuned=True)
+    again = art.profile_guided(spec.args, spec.extent)
+    assert again.header_path == by_hand.header_path and again.stage_info["regrouped"] == by_hand.stage_info["regrouped"] != []
+    assert not art.stage_info["regrouped"]
+    from inflatox_amd.compiler import CompilationArtifact
+
+    with pytest.raises(ValueError):
+        CompilationArtifact({}, "/nonexistent", 2, 0, auto_cleanup=False).profile_guided(spec.args, spec.extent)

@@ -84,3 +84,59 @@ def test_reference_documentation_known_answers(gpu_lib, tuned):
     assert np.allclose(al.calc_H(np.array([2.0, -2.0]), np.array([1.0])), np.array([[0.41206897, -1.05517241], [-1.05517241, -0.07873563]]))
     cons = al.complete_analysis(spec.args, 0.0, 2.5, 0.0, np.pi, progress=False)[0]
     assert np.nanmax(cons) <= 1
+
+
+def test_front_end_builds_the_profile_guided_code_object_from_its_first_sweep(gpu_lib):
+    """``GeneralisedAL(art, tuned=True)``: no hand-written sample -- the first sweep's own arguments (parameter values, field
+    range) are what ``Compiler(regroup="auto", sample=...)`` measures on (reference consistency_conditions.py:226-308: the call
+    supplies them).  EGNO 4096^2: the tuned object's device time is that of the hand-made profile-guided build (well below
+    the default build's), its results pass the parity criterion, and a ``tuned=False`` object returns the default build's
+    bits as before."""
+    import torch
+    import workloads
+    from inflatox_amd.consistency_conditions import GeneralisedAL, InflationCondition
+
+    spec, art = workloads.artifact_for("egno")
+
+    def front_end(tuned):
+        al = GeneralisedAL.__new__(GeneralisedAL)  # (without the constructor's random basis draw, like conftest.generalised_al)
+        InflationCondition.__init__(al, art, validate_basis=False, tuned=tuned)
+        return al
+
+    plain, tuned = front_end(False), front_end(True)
+    assert tuned.tuned_on is None
+    n0, n1 = 96, 130
+    a = np.stack(plain.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False), axis=-1)
+    b = np.stack(tuned.complete_analysis(spec.args, *spec.extent, n0, n1, progress=False), axis=-1)
+    assert tuned.tuned_on is not None and np.array_equal(tuned.tuned_on[0], spec.args) and tuned.tuned_on[1] == tuple(spec.extent)
+    assert set(tuned.artifact.stage_info["regrouped"]) == EXPECTED["egno"] and not plain.artifact.stage_info["regrouped"]
+    # the very code object workloads.artifact_for(name, tuned=True) builds by hand (same content tag): nothing was measured twice
+    _, by_hand = workloads.artifact_for("egno", tuned=True)
+    assert tuned.artifact.header_path == by_hand.header_path
+    # default object: the default build's bits; tuned object: other bits, inside the parity criterion
+    spec0, art0, lib0 = T.devlib("egno", gpu_lib)
+    assert np.array_equal(a, lib0.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1), equal_nan=True)
+    assert not np.array_equal(a, b, equal_nan=True)
+    import oracle
+
+    T.judge("egno", spec.args, oracle.grid_points(spec.extent, n0, n1), (n0, n1), T.grid_refs("egno", T.OP.COMPLETE, spec.args, spec.extent, n0, n1), b, T.tol.epilogue, "egno/front end tuned=True")
+    # device time at 4096^2 through the front end (complete_analysis_device: nothing crosses PCIe)
+    def device_ms(al):
+        best = float("inf")
+        for _ in range(3):
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(20):
+                res = al.complete_analysis_device(spec.args, *spec.extent, 4096, 4096)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20)
+            del res
+        return best
+
+    ms_plain, ms_tuned = device_ms(plain), device_ms(tuned)
+    assert ms_tuned < 0.92 * ms_plain, (ms_plain, ms_tuned)  # round 4: 0.40 vs 0.32 ms
+    # a later sweep elsewhere keeps the build; retune() measures again
+    tuned.complete_analysis(spec.args * 1.01, *spec.extent, 32, 32, progress=False)
+    assert np.array_equal(tuned.tuned_on[0], spec.args)

@@ -170,12 +170,12 @@ def allowance_derived(ref_raw: np.ndarray, env: np.ndarray, fn, model: str | Non
             worst = np.maximum(worst, d)
         # a model value whose own error is unbounded (singular point) leaves the outputs unconstrained
         worst[np.any(~np.isfinite(env), axis=-1)] = np.inf
-        # ... and so does one whose allowance exceeds its own magnitude: the reference does not even settle its SIGN there, the
-        # outputs are not monotonic over a box that contains zero, and its corners say nothing about its interior.  (Found
-        # with the clang-built reference: on D5's lines theta = k pi the gcc build returns v10 = 7e-22 and the clang build
-        # v10 = -v00 = -0.0997 -- E = 0.0997 --; `consistency` is 1.0 for the former, 6e-6 for the latter and ~1 again at
-        # both corners v10 = +-64 E.)
-        worst[np.any(delta > np.abs(ref_raw), axis=-1)] = np.inf
+        # ... and so does a DENOMINATOR of the per-point formulas (V, v00, v10: src/anguelova.rs:103-135 divides by each of them)
+        # whose allowance exceeds its own magnitude: the box then contains a pole of the outputs, they are not monotonic over
+        # it, and its corners say nothing about its interior.  (Found with the clang-built reference: on D5's lines theta = k pi
+        # the gcc build returns v10 = 7e-22 and the clang build v10 = -v00 = -0.0997 -- E = 0.0997 --; `consistency` is 1.0 for
+        # the former, 6e-6 for the latter and ~1 again at both corners v10 = +-64 E.)
+        worst[np.any((delta > np.abs(ref_raw))[..., :3], axis=-1)] = np.inf
         return RTOL * np.abs(base) + 2.0 * worst
 
 
