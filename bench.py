@@ -320,7 +320,8 @@ def next_rows(_native, workloads, torch, np, device, stream):
         device_sweep("f1", "hyperbolic", op, 8192, _native.LAYOUT_AOS, f"{name} (src/anguelova.rs:138-163), one f64 per point", 1)
     device_sweep("f1", "doc", _native.OP_CONSISTENCY, 4096, _native.LAYOUT_AOS, "consistency_only, one f64 per point", 1)
     device_sweep("f1", "doc", _native.OP_EPSILON_V, 4096, _native.LAYOUT_AOS, "epsilon_v_only, one f64 per point", 1)
-    device_sweep("f3", "doc", _native.OP_RAW, 4096, _native.LAYOUT_SOA, "V, v00, v10, v11, |dV|^2 as five planes (what calc_V_array / calc_H_array read)", 5)
+    device_sweep("f3", "doc", _native.OP_RAW, 4096, _native.LAYOUT_SOA, "V, v00, v10, v11, |dV|^2 as five planes (what calc_V_array reads)", 5)
+    device_sweep("f3", "doc", _native.OP_HESSE, 4096, _native.LAYOUT_SOA, "v00, v01, v10, v11 as four planes (calc_H_array: the reference's own v01)", 4)
     torch.cuda.empty_cache()
     try:  # f2: the on-trajectory call of the reference's trajectory fixtures' size, and a long one
         spec, art = workloads.artifact_for("doc")

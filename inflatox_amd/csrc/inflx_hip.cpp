@@ -611,13 +611,6 @@ size_t tile_height(size_t full, size_t segments) {
   return std::min(full, std::max<size_t>({size_t(1), std::min(full / 2, segments / kLaunchWorkgroups), segments / (4 * kLaunchWorkgroups)}));
 }
 
-// Vertically consecutive tiles per workgroup of a launch of `tiles` full- or part-height tiles: 1 until the measurement says otherwise
-// (scripts/tiles_per_wg_probe.py).
-size_t tiles_per_workgroup(size_t tiles, bool full_height) {
-  (void)tiles, (void)full_height;
-  return 1;
-}
-
 int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_params, size_t P, double* d_out, size_t N1, size_t row_count, hipStream_t s,
                  double* d_stats) {
   void* params[] = {&a};
@@ -673,16 +666,7 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
         if (rows > 0) th = std::min<size_t>(full, (size_t)rows);
       }
       a.tile_rows = (uint32_t)th;
-      // tiles one workgroup walks one after the other (kernel: `tiles_per_wg`).  Experiments: INFLX_EXPERIMENT_TILES_PER_WG.
-      size_t per_wg = tiles_per_workgroup(gx * ((slab + th - 1) / th) * pb, th == full);
-      static const bool forced_tiles = getenv("INFLX_EXPERIMENT_TILES_PER_WG") != nullptr;
-      if (forced_tiles) {
-        const char* e = getenv("INFLX_EXPERIMENT_TILES_PER_WG");
-        const int n = e ? atoi(e) : 0;
-        if (n > 0) per_wg = (size_t)n;
-      }
-      a.reserved0 = (uint32_t)per_wg;
-      const size_t gy = ((slab + th - 1) / th + per_wg - 1) / per_wg;
+      const size_t gy = (slab + th - 1) / th;
       HIP_TRY(probe_begin(m, s));
       HIP_TRY(hipModuleLaunchKernel(f, (unsigned)gx, (unsigned)gy, (unsigned)pb, m->info.tile_cols, 1, 1, 0, s, params, nullptr));
       HIP_TRY(probe_end(m, s));

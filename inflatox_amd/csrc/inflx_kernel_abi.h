@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 18u
+#define INFLX_KERNEL_ABI 17u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -65,7 +65,6 @@ struct InflxSweepArgs {
   // height; a grid with fewer full-height tiles than the chip has wavefront slots is cut into lower tiles, so that a
   // 256 x 256 or 1000 x 1000 sweep is not eight (128) workgroups walking 32 rows each one after the other
   uint32_t tile_rows;
-  // tile kernels: vertically consecutive tiles one workgroup walks (0 or 1: one tile per workgroup); grid.y = ceil(tiles / this)
   uint32_t reserved0;
 };
 

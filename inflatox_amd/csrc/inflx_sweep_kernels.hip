@@ -341,19 +341,29 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   const double* __restrict__ utab = a.row_table + (uint64_t)p * kNU;
   const double* __restrict__ rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNRs;
   const double* __restrict__ ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNRs) + (uint64_t)p * kNC * a.N1;
-  const uint64_t col0 = (uint64_t)blockIdx.x * kThreads;
+  // Which 256 columns does this workgroup own?  Workgroups are dealt to the 8 XCDs round-robin in launch order -- XCD = linear id
+  // mod 8 = blockIdx.x mod 8 for the usual multiples of 8 column tiles -- and every XCD schedules only what it was dealt.  With
+  // column tile = blockIdx.x a column tile that is structurally slow (D5: the column x1 = 0, where sin(theta) = 0 exactly sends its
+  // wavefront through the IEEE loop in every row, 1.4 x the time, while the workgroup's other slots wait) lands on ONE XCD in every
+  // grid row and parameter row: that XCD finishes last and the other seven idle (round 5: 12 % of D5's wave slots empty with no
+  // workgroup held back by any resource, profiles/r05_experiments.txt sections 3 and 7).  Rotating the column tile with the grid
+  // row and the parameter row gives every XCD every column tile equally often.  Same tiles, same values, another owner.
+#ifndef INFLX_XCD_SPREAD
+#define INFLX_XCD_SPREAD 1
+#endif
+#if INFLX_XCD_SPREAD
+  const unsigned col_tile = (blockIdx.x + blockIdx.y + blockIdx.z) % gridDim.x;
+#else
+  const unsigned col_tile = blockIdx.x;
+#endif
+  const uint64_t col0 = (uint64_t)col_tile * kThreads;
   const uint64_t j = col0 + tid;
   const double x1 = inflx_coord(j, a.dx1, a.x1a);
   // relative to row_begin; stream_row0 = first slab row of this launch (grid.y is limited to 65535 tiles)
   const unsigned tile_rows = a.tile_rows;  // height of this launch's tiles (<= kTileRows; lower for small grids)
-  // A workgroup walks `tiles_per_wg` vertically consecutive tiles of its 256 columns (same parameter row): its column values, its
-  // parameter-only values and the epilogue's coefficients are loaded once, only the 32 rows of R values are restaged per tile --
-  // and the wave slots it holds stay filled across what would otherwise be that many workgroup hand-overs (round 5: SQ_WAVE_CYCLES
-  // puts D5's mean occupancy at 2.64 of 3 wavefronts per SIMD while the SPI never has a workgroup waiting that does not fit).
-  const unsigned tiles_per_wg = a.reserved0 ? a.reserved0 : 1u;
-  uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * tiles_per_wg * tile_rows;
-  uint64_t left = a.row_count - row0;
-  int nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
+  const uint64_t row0 = (uint64_t)a.stream_row0 + (uint64_t)blockIdx.y * tile_rows;
+  const uint64_t left = a.row_count - row0;
+  const int nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
 #ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE  // (A/B experiment only: the round-1 prologue, every workgroup evaluates its own stage values)
 #if INFLX_U_IN_LDS
   __shared__ __attribute__((aligned(16))) double U[kNU];
@@ -383,7 +393,7 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
 #pragma unroll
   for (int k = 0; k < kNC; ++k) C[k] = j < a.N1 ? ctab[(uint64_t)k * a.N1 + j] : 0.0;
   {
-    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * tiles_per_wg * tile_rows * kNRs;
+    const double* __restrict__ src = rtab + (uint64_t)blockIdx.y * tile_rows * kNRs;
     double* dst = &Rs[0][0];
     for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
   }
@@ -481,7 +491,10 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   // 4096 columns); after two consecutive irregular rows it therefore stops trying and leaves the remaining rows
   // to the IEEE loop directly.
   static_assert(kTileRows <= 64, "one bit per tile row");
-  for (unsigned tile = 0;; ++tile) {
+  // (One workgroup per tile.  A workgroup that walks several vertically consecutive tiles -- column values, parameter-only values
+  // and coefficients loaded once, R rows restaged behind a barrier, wave slots held across the hand-over -- was measured in round 5,
+  // bit-identical results: D5 4096^2 x 32 14.06 ms with 1 tile, 14.44 / 14.84 / 15.83 with 2 / 4 / 8; EGNO x 32 13.10 / 13.05 /
+  // 13.13 / 13.43; doc x 16 3.47 / 3.47 / 3.44 / 3.49 -- profiles/r05_experiments.txt section 4.)
   uint64_t redo = 0;
   int streak = 0;  // consecutive irregular rows (wave-uniform)
   for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
@@ -526,27 +539,6 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     double o[K];
     apply_op<OP, kTable>(mv, o, a.accuracy, kc);
     emit(o, row);
-  }
-  // the next tile of this workgroup: its rows of R values replace this tile's once every wavefront is done reading them
-  if (tile + 1 >= tiles_per_wg) break;
-  row0 += tile_rows;
-  if (row0 >= (uint64_t)a.stream_row0 + a.stream_units || row0 >= a.row_count) break;  // (workgroup-uniform)
-  left = a.row_count - row0;
-  nrows = left < (uint64_t)tile_rows ? (int)left : (int)tile_rows;
-  __syncthreads();
-  {
-#ifdef INFLX_EXPERIMENT_INLINE_PROLOGUE
-    if ((int)tid < nrows) inflx_stage_row(inflx_coord(a.row_begin + row0 + tid, a.dx0, a.x0a), A, U, Rs[tid]);
-#else
-    const double* __restrict__ src = rtab + (row0 - a.stream_row0) * kNRs;
-    double* dst = &Rs[0][0];
-    for (unsigned i = tid; i < (unsigned)(nrows * kNRs); i += kThreads) dst[i] = src[i];
-#endif
-  }
-  __syncthreads();
-#if INFLX_DRAIN_LOADS_BEFORE_ROW_LOOP
-  __builtin_amdgcn_s_waitcnt(0x0F70);  // (see above: the row loop must not wait on this tile's table loads behind its stores)
-#endif
   }
   if constexpr (STATS) stat_flush(acc, a.stats);
 }
