@@ -1326,3 +1326,25 @@ def test_tile_launch_plan_of_typical_grids(gpu_lib):
     # more than 65535 full-height tiles of rows: several launches
     tall = lib.sweep_plan(gpu_lib.OP_COMPLETE, 1, 2, 2100001)
     assert tall["batches"] == 2 and tall["tile_rows"] == full
+
+
+@pytest.mark.parametrize("name", ["doc", "d5"])
+def test_xcd_rotation_of_the_column_tiles_changes_no_bit(name, gpu_lib):
+    """The tile kernels own column tile (blockIdx.x + blockIdx.y + blockIdx.z) mod gridDim.x instead of blockIdx.x, so that a
+    structurally slow column tile does not land on one XCD in every grid row.  Another owner for the same
+    tile: a build with the identity map (-DINFLX_XCD_SPREAD=0) returns the same bits -- ragged grids, 1 / 4 / 5 / 17 column tiles,
+    several tile rows, a parameter batch, AoS and planes, a single-value operation."""
+    import workloads
+    from inflatox_amd.compiler import Compiler
+
+    spec, art, lib = devlib(name, gpu_lib)
+    plain = Compiler(workloads.model_for(name), silent=True, compiler_flags=list(Compiler.default_hipcc_flags) + ["-DINFLX_XCD_SPREAD=0"], **spec.compiler_kwargs).compile()
+    assert plain.header_path != art.header_path
+    lib0 = gpu_lib.InflatoxDevLib(plain.shared_object_path)
+    rng = np.random.default_rng(8)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.9, 1.1, size=(3, len(spec.args)))
+    for n0, n1, P in ((70, 200, 1), (129, 1000, 3), (45, 1281, 2), (300, 4200, 1)):
+        for op, layout in ((gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_AOS), (gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_SOA), (gpu_lib.OP_EPSILON_V, gpu_lib.LAYOUT_AOS)):
+            a = lib.sweep_host(op, rows[:P], spec.extent, n0, n1, layout=layout)
+            b = lib0.sweep_host(op, rows[:P], spec.extent, n0, n1, layout=layout)
+            assert np.array_equal(a, b, equal_nan=True), (name, n0, n1, P, op, layout)
