@@ -162,14 +162,14 @@ def test_column_only_model_takes_the_column_broadcast_path(gpu_lib):
 
 # ---- the reference's own v01 (Hesse2D loads fns = [v00, v01, v10, v11], hesse_bindings.rs:202-210; `hesse` returns all four) ----
 def _with_a_v01_of_its_own(name="abs_and_sign"):
-    """A model whose v01 is NOT the expression tree of v10: the same function, written differently (expanded), as a
+    """A model whose v01 is NOT the expression tree of v10: the same function, written differently (common factors pulled out), as a
     symbolic stage leaves it when a simplification succeeds on one component and times out on the other."""
     import copy
 
     model, args, ext = _build(name)
     model = copy.copy(model)
     h = [list(row) for row in model.hesse_cmp]
-    h[0][1] = sp.expand(h[1][0]) if sp.expand(h[1][0]) != h[1][0] else sp.factor(h[1][0])
+    h[0][1] = sp.factor_terms(h[1][0])  # the same function with common factors pulled out of its sums: another tree, other roundings
     assert h[0][1] != h[1][0]
     model.hesse_cmp = h
     model.model_name = name + "_v01"
