@@ -2276,7 +2276,10 @@ int inflx_sweep_allgather_multi_ex(inflx_multi* mm, int op, const double* p, siz
     for (size_t k = 0; k < world; ++k)
       for (size_t j = k + 1; j < world; ++j)
         if (d_full[k] == d_full[j]) return fail(INFLX_ERR_ARG, "the RCCL all-gather needs a buffer per device (buffers %zu and %zu are the same)", k, j);
-    if (!(api = rccl_api())) return fail(INFLX_ERR_DEVICE, "RCCL (librccl.so) could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+    if (!(api = rccl_api())) {
+      const char* why = dlerror();  // (one call: dlerror() clears the message it returns)
+      return fail(INFLX_ERR_DEVICE, "RCCL (librccl.so) could not be loaded: %s", why ? why : "library or symbols missing");
+    }
     if ((rc = ensure_comms(mm, api))) return rc;
   } else if ((rc = ensure_push_streams(mm))) {
     return rc;

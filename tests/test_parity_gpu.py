@@ -1348,3 +1348,31 @@ def test_xcd_rotation_of_the_column_tiles_changes_no_bit(name, gpu_lib):
             a = lib.sweep_host(op, rows[:P], spec.extent, n0, n1, layout=layout)
             b = lib0.sweep_host(op, rows[:P], spec.extent, n0, n1, layout=layout)
             assert np.array_equal(a, b, equal_nan=True), (name, n0, n1, P, op, layout)
+
+
+@pytest.mark.parametrize("name", MODELS)
+def test_hesse_operation_is_the_raw_values_with_the_references_v01(name, gpu_lib):
+    """INFLX_OP_HESSE = (v00, v01, v10, v11) on every path a model can take (tile, row-broadcast, trajectory; AoS and planes): v00, v10,
+    v11 are the raw-values sweep's bit for bit, and v01 -- for these five models the very expression tree of v10 in the reference's
+    symbolic output -- equals the reference's own C function v01 as stored with the goldens (both builds), under the criterion of the
+    model values with v10's measured error."""
+    spec, art, lib = devlib(name, gpu_lib)
+    assert art.stage_info["v01_is_v10"]
+    g = golden(name)
+    tag = "g64"
+    n0, n1 = (int(v) for v in g[f"{tag}_shape"])
+    ext = g[f"{tag}_extent"]
+    raw = lib.sweep_host(gpu_lib.OP_RAW, g["args"], ext, n0, n1)
+    aos = lib.sweep_host(gpu_lib.OP_HESSE, g["args"], ext, n0, n1)
+    soa = lib.sweep_host(gpu_lib.OP_HESSE, g["args"], ext, n0, n1, layout=gpu_lib.LAYOUT_SOA)
+    assert aos.shape == (n0, n1, 4) and soa.shape == (4, n0, n1)
+    assert np.array_equal(np.moveaxis(soa, 0, -1), aos, equal_nan=True)
+    assert np.array_equal(aos[..., [0, 2, 3]], raw[..., 1:4], equal_nan=True) and np.array_equal(aos[..., 1], aos[..., 2], equal_nan=True)
+    pts = oracle.grid_points(ext, n0, n1)
+    assert np.array_equal(lib.sweep_on_trajectory(gpu_lib.OP_HESSE, g["args"], pts).reshape(n0, n1, 4), aos, equal_nan=True)
+    env, flaky = tol.reference_error(name, g["args"], pts)
+    env, flaky = env.reshape(n0, n1, 5)[..., 2], flaky.reshape(n0, n1, 5)[..., 2]
+    for cc in COMPILERS:
+        v01 = g[golden_key(f"{tag}_v01", cc)]
+        allowed = tol.RTOL * np.abs(v01) + tol.kappa_for(name) * env
+        tol.check(aos[..., 1], v01, allowed, flaky, f"{name}/{tag}/v01", model=name, against=cc)
