@@ -116,3 +116,12 @@ def test_random_model_on_the_gpu(seed, gpu_lib):
     pts = oracle.grid_points(ext, n0, n1)
     for k, row in enumerate((p, p * 1.1)):
         assert np.array_equal(six[k].reshape(-1, 6), lib.sweep_on_trajectory(gpu_lib.OP_COMPLETE, row, pts), equal_nan=True), (seed, k)
+    # the quick point stage forced on (hoisted reciprocals + Markstein step, quick square roots, IEEE redo of rows that fail a range
+    # test): exact by construction -- the same bits as the default build, on a grid that includes the rows / columns through 0
+    quick = Compiler(model, silent=True, cse=cse, hoist_reciprocals=True).compile()
+    lib_q = gpu_lib.InflatoxDevLib(quick.shared_object_path)
+    wide = (-ext[1], ext[1], -ext[3], ext[3])
+    for e, shape in ((ext, (n0, n1)), (wide, (64, 258))):
+        a = lib.sweep_host(gpu_lib.OP_COMPLETE, p, e, *shape)
+        b = lib_q.sweep_host(gpu_lib.OP_COMPLETE, p, e, *shape)
+        assert np.array_equal(a, b, equal_nan=True), (seed, shape)
