@@ -635,6 +635,9 @@ def main():
                 "parameter_rows_total": total_rows,
                 "baseline_config": "configs[1]" if total_rows == 1 else ("configs[4]" if (total_rows, N0) == (512, 8192) else f"configs[4] axis, first {total_rows} of 512 rows"),
                 "parallelism": (f"parameter-axis x{world} (plan_shard, no data-path collective)" if world > 1 else "single GPU") + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearse else ""),
+                # what "parity" means for the numbers on this line (tests/tolerance.py, profiles/r05_parity_stats.json)
+                "parity": "this workload's model (README hyperbolic): six arrays within the literal 1e-10 of the reference's C as gcc AND as clang build it, NaN/Inf exact (measured 4e-16); "
+                "roofline.configs models (D5, EGNO, doc): 1e-10 + a multiple of the reference's own measured rounding error -- its gcc and clang builds differ from each other by up to 4e-5 there",
             },
             "ranks": world,
             "comm_backend": (dist.get_backend() if distributed else None),
