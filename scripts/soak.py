@@ -19,7 +19,7 @@ from inflatox_amd import _native  # noqa: E402
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 rng = np.random.default_rng(seed)
-OPS = [(_native.OP_COMPLETE, 6), (_native.OP_CONSISTENCY, 1), (_native.OP_RAW, 5), (_native.OP_EPSILON_V, 1), (_native.OP_RAPIDTURN, 1)]
+OPS = [(_native.OP_COMPLETE, 6), (_native.OP_CONSISTENCY, 1), (_native.OP_RAW, 5), (_native.OP_EPSILON_V, 1), (_native.OP_RAPIDTURN, 1), (_native.OP_HESSE, 4)]
 libs = {}
 for name in ("hyperbolic", "doc", "d5", "egno"):
     spec, art = workloads.artifact_for(name)

@@ -1376,3 +1376,39 @@ def test_hesse_operation_is_the_raw_values_with_the_references_v01(name, gpu_lib
         v01 = g[golden_key(f"{tag}_v01", cc)]
         allowed = tol.RTOL * np.abs(v01) + tol.kappa_for(name) * env
         tol.check(aos[..., 1], v01, allowed, flaky, f"{name}/{tag}/v01", model=name, against=cc)
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_degenerate_parameter_values(name, gpu_lib):
+    """Parameters a model was not written for -- zero, negative, infinite, NaN, so large that powers overflow, so small that products
+    are denormal or underflow to zero: the sweep must return what the reference's C returns, NaN for NaN and Inf for Inf with its
+    sign (no flush-to-zero, no fast-math), finite values within the literal 1e-10 -- against both builds of the reference."""
+    spec, art, lib = devlib(name, gpu_lib)
+    base = np.asarray(spec.args, dtype=np.float64)
+    specials = [0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 1e200, 1e-200, 5e-324, 1e-160, 3e154, -2.5]
+    rows = []
+    for k in range(base.size):
+        for v in specials:
+            row = base.copy()
+            row[k] = v
+            rows.append(row)
+    rows = np.array(rows)
+    n0, n1 = 33, 70
+    ext = spec.extent
+    got = lib.sweep_host(gpu_lib.OP_COMPLETE, rows, ext, n0, n1)
+    got_raw = lib.sweep_host(gpu_lib.OP_RAW, rows, ext, n0, n1)
+    for cc in COMPILERS:
+        om, _ = oracle_model(name, cc)
+        for k, row in enumerate(rows):
+            want_raw = om.grid_sweep(OP.RAW, row, ext, n0, n1)
+            compare(got_raw[k], want_raw, 1e-10, f"{name}/raw with parameters {row} [{cc}]")
+            want = om.grid_sweep(OP.COMPLETE, row, ext, n0, n1)
+            # the six outputs follow from the model values by the same operations on both sides; where the model values agree to 1e-10
+            # but an output is a difference of nearly equal terms the comparison is relative to the output's own scale
+            assert np.array_equal(np.isnan(got[k]), np.isnan(want)), f"{name}: NaN pattern with parameters {row} [{cc}]"
+            inf = np.isinf(want)
+            assert np.array_equal(np.isinf(got[k]), inf) and np.array_equal(got[k][inf], want[inf]), f"{name}: Inf pattern with parameters {row} [{cc}]"
+            fin = np.isfinite(want)
+            if fin.any():
+                err = np.abs(got[k][fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)
+                assert err.max() <= 1e-9, f"{name}: parameters {row} [{cc}]: max relative error {err.max():.3e}"
