@@ -1412,3 +1412,22 @@ def test_degenerate_parameter_values(name, gpu_lib):
             if fin.any():
                 err = np.abs(got[k][fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)
                 assert err.max() <= 1e-9, f"{name}: parameters {row} [{cc}]: max relative error {err.max():.3e}"
+
+
+def test_unusual_extents(gpu_lib):
+    """Ranges the index -> coordinate map (src/anguelova.rs:84-94, 531-533) accepts like any other: reversed (negative spacing), empty
+    (start == stop: every point the same), far from the origin, tiny -- hyperbolic at the literal 1e-10 against both builds, the doc
+    model on a reversed and an empty range under the measured-error criterion."""
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    for ext in ((1.0, -1.0, 1.0, -1.0), (0.5, 0.5, -1.0, 1.0), (-3.0, 7.0, 2.0, 2.0), (1e3, 1e3 + 1e-9, 0.0, 1e-300), (-1e-12, 1e-12, -1.0, 1.0), (30.0, 700.0, 0.0, 1.0)):
+        for n0, n1 in ((17, 33), (1, 1), (300, 2)):
+            got = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, n0, n1)
+            for cc in COMPILERS:
+                om, _ = oracle_model("hyperbolic", cc)
+                compare(got, om.grid_sweep(OP.COMPLETE, spec.args, ext, n0, n1), 1e-10, f"hyperbolic extent {ext} {n0}x{n1} [{cc}]")
+    spec, art, lib = devlib("doc", gpu_lib)
+    x0a, x0b, x1a, x1b = spec.extent
+    for ext in ((x0b, x0a + 0.3, x1b, x1a), (1.7, 1.7, 0.4, 0.4), (x0a + 0.3, x0b, 2.0, 2.0)):
+        n0, n1 = 40, 70
+        got = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, n0, n1)
+        judge("doc", spec.args, oracle.grid_points(ext, n0, n1), (n0, n1), grid_refs("doc", OP.COMPLETE, spec.args, ext, n0, n1), got, tol.epilogue, f"doc extent {ext}")
