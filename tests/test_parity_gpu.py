@@ -1431,3 +1431,23 @@ def test_unusual_extents(gpu_lib):
         n0, n1 = 40, 70
         got = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, ext, n0, n1)
         judge("doc", spec.args, oracle.grid_points(ext, n0, n1), (n0, n1), grid_refs("doc", OP.COMPLETE, spec.args, ext, n0, n1), got, tol.epilogue, f"doc extent {ext}")
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc"])
+def test_trajectory_points_with_special_coordinates(name, gpu_lib):
+    """On-trajectory sweeps (src/anguelova.rs:633-977) take whatever points they are given: NaN and infinite coordinates, zeros of
+    both signs, the far field, denormals -- same NaN / Inf pattern and (where finite) the same values as the reference's C, both builds."""
+    spec, art, lib = devlib(name, gpu_lib)
+    s = np.array([0.0, -0.0, np.nan, np.inf, -np.inf, 1e-310, -1e-310, 1e300, -1e300, 1.0, -1.0, 0.5, 710.0, -710.0, 1e-8])
+    pts = np.array([(a, b) for a in s for b in s])
+    for gop, oop in ((gpu_lib.OP_RAW, OP.RAW), (gpu_lib.OP_COMPLETE, OP.COMPLETE)):
+        got = lib.sweep_on_trajectory(gop, spec.args, pts)
+        for cc in COMPILERS:
+            om, _ = oracle_model(name, cc)
+            want = om.trajectory_sweep(oop, spec.args, pts)
+            assert np.array_equal(np.isnan(got), np.isnan(want)), f"{name}: NaN pattern [{cc}] at {pts[np.argwhere(np.isnan(got) != np.isnan(want))[0][0]]}"
+            inf = np.isinf(want)
+            assert np.array_equal(np.isinf(got), inf) and np.array_equal(got[inf], want[inf]), f"{name}: Inf pattern [{cc}]"
+            fin = np.isfinite(want)
+            err = np.abs(got[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)
+            assert err.max() <= 1e-9, f"{name} [{cc}]: {err.max():.3e}"
