@@ -44,7 +44,7 @@ FP64_LANE_RATE = 256 * 4 * 16 * 2.4e9  # FP64 VALU lane-instructions/s at full r
 BYTES_PER_POINT = 48  # 6 x f64 written, 0 read
 # parameter-row sweeps (8192^2 each, ~0.45 ms) run untimed before the warm-up steps so that the clocks have settled: 64 = 29 ms
 SETTLE_ROW_SWEEPS = 64
-PROFILE_ROUNDS = ("05", "04", "03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json, rNN_isa_mix.json: newest first
+PROFILE_ROUNDS = ("06", "05", "04", "03", "02", "01")  # profiles/rNN_traffic.json, rNN_valu.json, rNN_isa_mix.json: newest first
 SIMDS = 256 * 4
 
 
@@ -201,8 +201,11 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                 # run inside the clock governor's transient (the warm-up of these side measurements, like --warmup for the steps)
                 lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats)
                 ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
+                # ... and what ONE call costs a user whose handle is idle (one call = one sweep, reference consistency_conditions.py:290-300):
+                # HIP events around stage tables + tile kernel, the device drained before every call (INFLX_TIME_SINGLE_CALL)
+                ms_single = min(lib.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=max(3, repeats // 2), single_call=True) for _ in range(3))
             else:  # scripts/secondary_probe.py NAME:tuned -- only the profile-guided build under the profiler
-                ms = float("nan")
+                ms = ms_single = float("nan")
             pps = P * n * n / (ms * 1e-3)
             cid = code_object_id(art)
             valu, src = recorded("valu", name, cid)
@@ -212,6 +215,8 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                 "build": "default: the reference's arithmetic (Compiler(...) as the reference's tests call it; tan_shortcut off: eta is OCML's tan of OCML's atan)",
                 "ms": ms,
                 "timing": f"HIP events around {repeats} back-to-back launches, best of 3 such batches",
+                "single_call_ms": ms_single,
+                "single_call_timing": f"one sweep from an idle handle, HIP events around stage tables + tile kernel, mean of {max(3, repeats // 2)} calls, best of 3 such batches",
                 "points_per_s": pps,
                 "hbm_frac": BYTES_PER_POINT * pps / 1e9 / HBM_PEAK_GBPS,
                 "code_object": cid,
@@ -239,7 +244,9 @@ def secondary_workloads(_native, workloads, torch, np, device, stream, only=None
                 lib_t = _native.InflatoxDevLib(art_t.shared_object_path, device=device)
                 lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats)  # untimed batch, as above
                 ms_t = min(lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=repeats) for _ in range(3))
+                ms_t_single = min(lib_t.sweep_device_timed(_native.OP_COMPLETE, rows, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, stream=stream, repeats=max(3, repeats // 2), single_call=True) for _ in range(3))
                 rec["profile_guided"] = {
+                    "single_call_ms": ms_t_single,
                     "build": 'Compiler(regroup="auto", sample=(args, extent)): measured re-association, tan(atan t) -> t for t <= 16',
                     "regrouped_values": art_t.stage_info.get("regrouped"),
                     "ms": ms_t,
@@ -282,6 +289,53 @@ def configs_block(secondary):
                                       "frac_issue_weighted": (pg.get("roofline") or {}).get("frac_issue_weighted"), "code_object": pg["code_object"]}
         out[key] = cell
     return out
+
+
+def flat_configs(secondary):
+    """The same figures as FLAT SCALARS for `roofline` (the driver's record keeps scalar keys of `roofline` only): prefix c2_ =
+    BASELINE configs[2] (D5 4096^2 x 32 in one call), c3_ = configs[3] (EGNO 4096^2), doc_ = the doc model 4096^2.
+      *_ms                     device time per sweep, sweeps enqueued back to back (throughput of a scan: tables of sweep n+1 under sweep n)
+      *_single_call_ms         ONE sweep from an idle handle: HIP events around stage tables + tile kernel
+      *_points_per_s, *_hbm_frac (48 B/point / 8 TB/s), *_valu_frac_nominal (VALU instr/point x points/s / 39.3e12),
+      *_frac_issue_weighted    measured issue costs at the measured clock (self-defined ceiling, not the roofline of SURVEY 8d)
+      *_tuned_*                the profile-guided build (Compiler(regroup="auto")) of the same workload"""
+    prefix = {"D5-brane model": "c2", "EGNO supergravity model": "c3", "documentation model (reference tests/test_doc.py)": "doc"}
+    out = {}
+    for rec in secondary:
+        pre = prefix.get(rec.get("workload", "").split(",")[0])
+        if pre is None or "error" in rec:
+            continue
+        roof = rec.get("roofline") or {}
+        out[f"{pre}_ms"] = rec["ms"]
+        out[f"{pre}_single_call_ms"] = rec.get("single_call_ms")
+        out[f"{pre}_points_per_s"] = rec["points_per_s"]
+        out[f"{pre}_hbm_frac"] = rec["hbm_frac"]
+        out[f"{pre}_valu_frac_nominal"] = roof.get("frac")
+        out[f"{pre}_frac_issue_weighted"] = roof.get("frac_issue_weighted")
+        pg = rec.get("profile_guided")
+        if pg and "ms" in pg:
+            out[f"{pre}_tuned_ms"] = pg["ms"]
+            out[f"{pre}_tuned_single_call_ms"] = pg.get("single_call_ms")
+            out[f"{pre}_tuned_points_per_s"] = pg["points_per_s"]
+            out[f"{pre}_tuned_hbm_frac"] = pg["hbm_frac"]
+    return out
+
+
+def tile_path_on_configs1(_native, lib, torch, spec, n, device, stream):
+    """BASELINE configs[1] evaluated PER GRID POINT: the hyperbolic 8192^2 sweep forced through inflx_sweep_tile_complete
+    (INFLX_SWEEP_FORCE_TILE, an argument of inflx_sweep_device_timed_ex) -- one lane per grid point, every point evaluated, what
+    the reference's loop does (src/anguelova.rs:526-539) -- instead of the row-broadcast store stream the headline `value` is
+    measured on.  Same bytes written, same values (tests/test_parity_gpu.py: bit for bit at 8192^2)."""
+    buf = torch.empty((n, n, 6), dtype=torch.float64, device=f"cuda:{device}")
+    kw = dict(stream=stream, force_tile=True)
+    lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, repeats=20, **kw)  # untimed batch
+    ms = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, repeats=20, **kw) for _ in range(3))
+    single = min(lib.sweep_device_timed(_native.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, repeats=10, single_call=True, **kw) for _ in range(3))
+    plan = lib.sweep_plan(_native.OP_COMPLETE, 1, n, n, force_tile=True)
+    del buf
+    pps = n * n / (ms * 1e-3)
+    return {"c1_tile_path_ms": ms, "c1_tile_path_single_call_ms": single, "c1_tile_path_points_per_s": pps, "c1_tile_path_hbm_frac": BYTES_PER_POINT * pps / 1e9 / HBM_PEAK_GBPS,
+            "c1_tile_path_kernel": "inflx_sweep_tile_complete" if plan["path"] == "tile" else plan["path"]}
 
 
 def next_rows_block(rows):
@@ -568,6 +622,8 @@ def main():
     ms_kernel = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(2, min(opt.steps, 40 // rows_per_gpu)), in_pipeline=True) / rows_per_gpu
     # ... and the whole step (all rows of the block, every launch of the call), per parameter row
     ms_sweep = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(2, min(opt.steps, 40 // rows_per_gpu))) / rows_per_gpu
+    # ... and ONE call from an idle handle (per-row evaluation + store stream between two events, the device drained before each call)
+    ms_single = lib.sweep_device_timed(_native.OP_COMPLETE, args, out.data_ptr(), nbytes, spec.extent, N0, N1, stream=stream, repeats=max(2, min(opt.steps, 40 // rows_per_gpu)), single_call=True) / rows_per_gpu
     points = N0 * N1
     achieved = BYTES_PER_POINT * points / (ms_kernel * 1e-3) / 1e9
 
@@ -662,6 +718,7 @@ def main():
                 "kernel_timing": "HIP event pairs on the launch stream around every launch of the dominant kernel inside full steps (per parameter row); kernel_ms_isolated: the same kernel relaunched back to back on its own",
                 "kernel_ms_isolated": ms_kernel_isolated,
                 "sweep_ms": ms_sweep,  # whole step / parameter rows per step
+                "single_call_ms": ms_single,  # one call from an idle handle / parameter rows per call
                 "call_GBps": BYTES_PER_POINT * points / (ms_sweep * 1e-3) / 1e9,
                 "timed_region_ms_per_step_hip_events": step_ms_events,
                 "kernels_per_step": ["inflx_sweep_rowvals_complete", "inflx_sweep_rowstream6"] if row_path else ["inflx_sweep_tile_complete"],
@@ -681,6 +738,14 @@ def main():
             # the same figures in compact form inside `roofline`, the object the driver's record keeps whole
             line["roofline"]["configs"] = configs_block(line["secondary"])
             line["roofline"]["next_rows"] = next_rows_block(line["next_rows"])
+            # ... and as flat scalars, which is what the driver's parser keeps of `roofline` (round 5: the nested blocks were dropped)
+            line["roofline"].update(flat_configs(line["secondary"]))
+            if (opt.model, opt.n) == ("hyperbolic", 8192):
+                try:
+                    line["roofline"].update(tile_path_on_configs1(_native, lib, torch, spec, opt.n, local_rank, stream))
+                except Exception as exc:  # noqa: BLE001 -- a side figure must never cost the benchmark line
+                    line["roofline"]["c1_tile_path_error"] = str(exc)[:200]
+            line["roofline"]["host_threads_budget"] = _native.host_threads()["budget"]
             try:
                 line["end_to_end"] = end_to_end(workloads, np, opt.model, opt.n, local_rank)
             except Exception as exc:  # noqa: BLE001

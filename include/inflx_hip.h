@@ -190,6 +190,36 @@ typedef enum inflx_path {
 } inflx_path;
 int inflx_sweep_plan(const inflx_model* model, int op, size_t P, size_t N1, size_t row_count, int layout, uint32_t plan[4]);
 
+/*
+ * Per-call options of the device-result sweeps (the *_ex entry points; the plain ones pass INFLX_SWEEP_DEFAULT).
+ *   INFLX_SWEEP_FORCE_TILE  evaluate EVERY grid point in the tile kernels (one lane per grid point, inflx_sweep_tile_*), also for a
+ *                           model whose values ignore a grid axis and would otherwise take a broadcast path (one evaluated line
+ *                           + store stream).  That is what the reference does for every model -- its loop calls the five model
+ *                           functions at every point whatever they depend on (src/anguelova.rs:526-539) -- and the results are
+ *                           the broadcast path's bit for bit; the flag exists so that the per-lane rate of such a workload can be
+ *                           measured and the two paths compared (bench.py `c1_tile_path_*`, tests/test_parity_gpu.py).
+ */
+typedef enum inflx_sweep_flags {
+  INFLX_SWEEP_DEFAULT = 0,
+  INFLX_SWEEP_FORCE_TILE = 1
+} inflx_sweep_flags;
+int inflx_sweep_device_ex(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
+                          size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
+                          size_t row_count, int layout, void* stream, unsigned flags);
+int inflx_sweep_plan_ex(const inflx_model* model, int op, size_t P, size_t N1, size_t row_count, int layout, unsigned flags,
+                        uint32_t plan[4]);
+
+/*
+ * Host helper threads (no launch, no device needed).  The host-result paths start helper threads -- page residency ahead of the
+ * device-to-host copy, the streaming-store fill of results that are constant along a grid axis.  Their number comes from ONE
+ * budget per process, read once: the CPUs of the scheduler affinity mask, cut down to the smallest cgroup CPU quota between the
+ * process's cgroup and the root (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us); INFLX_HOST_THREADS overrides it.  The
+ * reference sizes its rayon pool the same way (`threads` = 0 -> every core the process has, src/anguelova.rs:467,524-525).  A
+ * multi-device call divides the budget among the devices at work.  out = {budget, residency helpers, fill helpers} of one device
+ * pipeline when `devices_at_work` pipelines run at once (0 is read as 1).
+ */
+int inflx_host_threads(unsigned devices_at_work, unsigned out[3]);
+
 /* As inflx_sweep_device, `repeats` times back to back between two HIP events recorded on the
  * launch stream; returns the mean duration of one sweep in milliseconds (synchronises).  A sweep of a
  * model whose values do not depend on x[1] is two launches (per-row evaluation, then the store stream);
@@ -201,6 +231,27 @@ int inflx_sweep_device_timed(inflx_model* model, int op, const double* p, size_t
                              size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
                              size_t row_count, int layout, void* stream, int repeats, int dominant_only,
                              float* ms_per_launch);
+/*
+ * The same with the timing mode by name and the inflx_sweep_flags of inflx_sweep_device_ex:
+ *   INFLX_TIME_BACK_TO_BACK   mode 0 above: `repeats` sweeps enqueued back to back between two events -- the THROUGHPUT of a scan:
+ *                             the tables (per-row values) of sweep n+1 are evaluated on a side stream under the kernels of sweep n;
+ *   INFLX_TIME_DOMINANT_ONLY  mode 1;   INFLX_TIME_IN_PIPELINE  mode 2;
+ *   INFLX_TIME_SINGLE_CALL    what ONE call costs a caller whose handle is idle (one call = one sweep, reference
+ *                             python/inflatox/consistency_conditions.py:290-300): before every repetition the call waits until
+ *                             nothing of this handle is left on the device, then brackets one whole inflx_sweep_device_ex call --
+ *                             stage tables / per-row evaluation AND the sweep kernel -- with two events on the launch stream;
+ *                             returns the mean over `repeats` calls.
+ */
+typedef enum inflx_timing {
+  INFLX_TIME_BACK_TO_BACK = 0,
+  INFLX_TIME_DOMINANT_ONLY = 1,
+  INFLX_TIME_IN_PIPELINE = 2,
+  INFLX_TIME_SINGLE_CALL = 3
+} inflx_timing;
+int inflx_sweep_device_timed_ex(inflx_model* model, int op, const double* p, size_t P, size_t n_p, void* d_out,
+                                size_t d_out_bytes, const double* start_stop, size_t N0, size_t N1, size_t row_begin,
+                                size_t row_count, int layout, void* stream, int repeats, int mode, unsigned flags,
+                                float* ms_per_launch);
 
 /*
  * Running summary of the six complete_analysis outputs over a sweep (no counterpart in the reference's

@@ -23,6 +23,8 @@ OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
 OP_HESSE = 6  # v00, v01, v10, v11: the projected Hesse matrix with the reference's own v01 (INFLX_SWEEP_HESSE)
 OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5, OP_HESSE: 4}
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
+SWEEP_DEFAULT, SWEEP_FORCE_TILE = 0, 1  # inflx_sweep_flags
+TIME_BACK_TO_BACK, TIME_DOMINANT_ONLY, TIME_IN_PIPELINE, TIME_SINGLE_CALL = range(4)  # inflx_timing
 GATHER_PEER_PUSH, GATHER_RCCL = 0, 1  # inflx_gather: the exchange step of inflx_sweep_allgather_multi_ex
 
 _DP = C.POINTER(C.c_double)
@@ -55,6 +57,16 @@ SIGNATURES = {
         C.c_int,
         [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_float)],
     ),
+    "inflx_sweep_device_ex": (
+        C.c_int,
+        [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p, C.c_uint],
+    ),
+    "inflx_sweep_device_timed_ex": (
+        C.c_int,
+        [C.c_void_p, C.c_int, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_uint, C.POINTER(C.c_float)],
+    ),
+    "inflx_sweep_plan_ex": (C.c_int, [C.c_void_p, C.c_int, _SIZE, _SIZE, _SIZE, C.c_int, C.c_uint, C.POINTER(C.c_uint32)]),
+    "inflx_host_threads": (C.c_int, [C.c_uint, C.POINTER(C.c_uint)]),
     "inflx_sweep_device_stats": (
         C.c_int,
         [C.c_void_p, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_void_p, C.c_void_p],
@@ -357,30 +369,36 @@ class InflatoxDevLib:
         _check(self._lib.inflx_sweep_host_planes(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, first_plane, n_planes))
         return out[0] if single else out
 
-    def sweep_device(self, op, p, d_out_ptr: int, d_out_bytes: int, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0):
-        """Enqueue a sweep whose result stays in device memory at ``d_out_ptr`` (no sync)."""
+    def sweep_device(self, op, p, d_out_ptr: int, d_out_bytes: int, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, force_tile: bool = False):
+        """Enqueue a sweep whose result stays in device memory at ``d_out_ptr`` (no sync).  ``force_tile``
+        (``INFLX_SWEEP_FORCE_TILE``): every grid point through the tile kernels, also for a model that ignores a grid axis."""
         p2 = _f64(p, "p")
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         row_count = N0 - row_begin if row_count is None else row_count
         _check(
-            self._lib.inflx_sweep_device(
-                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream)
+            self._lib.inflx_sweep_device_ex(
+                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream),
+                SWEEP_FORCE_TILE if force_tile else SWEEP_DEFAULT,
             )
         )
 
-    def sweep_device_timed(self, op, p, d_out_ptr, d_out_bytes, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, repeats: int = 10, dominant_only: bool = False, in_pipeline: bool = False) -> float:
-        """Mean duration (ms) of one sweep over ``repeats`` repetitions, HIP events on the launch stream;
+    def sweep_device_timed(self, op, p, d_out_ptr, d_out_bytes, start_stop, N0, N1, row_begin=0, row_count=None, layout=LAYOUT_AOS, stream: int = 0, repeats: int = 10, dominant_only: bool = False, in_pipeline: bool = False, single_call: bool = False, force_tile: bool = False) -> float:
+        """Mean duration (ms) of one sweep over ``repeats`` repetitions, HIP events on the launch stream.  Default: the sweeps
+        enqueued back to back (throughput of a scan: the tables of sweep n+1 are evaluated under the kernels of sweep n);
         ``dominant_only`` times just the dominant kernel of a multi-launch sweep, relaunched on its own; ``in_pipeline``
-        enqueues the full sweeps and returns the dominant kernel's time per sweep from event pairs around its launches."""
+        enqueues the full sweeps and returns the dominant kernel's time per sweep from event pairs around its launches;
+        ``single_call``: ONE whole call (tables / per-row values + sweep kernel) from an idle handle, mean over ``repeats`` calls."""
         p2 = _f64(p, "p")
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         row_count = N0 - row_begin if row_count is None else row_count
+        mode = TIME_SINGLE_CALL if single_call else (TIME_IN_PIPELINE if in_pipeline else (TIME_DOMINANT_ONLY if dominant_only else TIME_BACK_TO_BACK))
         ms = C.c_float(0.0)
         _check(
-            self._lib.inflx_sweep_device_timed(
-                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, 2 if in_pipeline else int(bool(dominant_only)), C.byref(ms)
+            self._lib.inflx_sweep_device_timed_ex(
+                self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, mode,
+                SWEEP_FORCE_TILE if force_tile else SWEEP_DEFAULT, C.byref(ms)
             )
         )
         return float(ms.value)
@@ -400,20 +418,30 @@ class InflatoxDevLib:
         )
         return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 
-    def sweep_plan(self, op, P, N1, row_count, layout=LAYOUT_AOS) -> dict:
+    def sweep_plan(self, op, P, N1, row_count, layout=LAYOUT_AOS, force_tile: bool = False) -> dict:
         """Which kernels a sweep of this shape takes: ``{"path": "tile"|"row_stream"|"rows"|"col_stream", "batch_rows", "batches", "replicas"}``;
         for the tile path ``batch_rows`` = parameter rows per launch, ``batches`` = launches, and ``tile_rows`` = grid rows per workgroup
-        tile of the first launch."""
+        tile of the first launch.  ``host_threads``: the process's host-thread budget and the helper threads a host-result call of this
+        handle starts (``inflx_host_threads``)."""
         plan = (C.c_uint32 * 4)()
-        _check(self._lib.inflx_sweep_plan(self._h, op, P, N1, row_count, layout, plan))
+        _check(self._lib.inflx_sweep_plan_ex(self._h, op, P, N1, row_count, layout, SWEEP_FORCE_TILE if force_tile else SWEEP_DEFAULT, plan))
         path = ("tile", "row_stream", "rows", "col_stream")[plan[0]]
         out = {"path": path, "batch_rows": int(plan[1]), "batches": int(plan[2]), "replicas": int(plan[3])}
         if path == "tile":
             out["tile_rows"] = out.pop("replicas")
+        out["host_threads"] = host_threads()
         return out
 
     def synchronize(self):
         _check(self._lib.inflx_synchronize(self._h))
+
+
+def host_threads(devices_at_work: int = 1) -> dict:
+    """``inflx_host_threads``: the process's CPU budget (affinity mask cut down to the cgroup quota) and the helper threads one device
+    pipeline of a host-result call starts when ``devices_at_work`` pipelines run at once (no device needed)."""
+    out = (C.c_uint * 3)()
+    _check(load_library().inflx_host_threads(int(devices_at_work), out))
+    return {"budget": int(out[0]), "residency": int(out[1]), "fill": int(out[2])}
 
 
 def shard_plan(P: int, N0: int, world: int, rank: int) -> dict:

@@ -30,6 +30,7 @@
 #include <thread>
 #include <vector>
 
+#include <sched.h>
 #include <sys/mman.h>
 #if defined(__x86_64__)
 #include <emmintrin.h>
@@ -83,13 +84,127 @@ size_t whole_result_limit() {
   }();
   return v;
 }
-unsigned prefault_threads() {
+// ---- one host-thread budget per process ---------------------------------------------------------------------------------
+// The helper threads of the host-result paths (page residency ahead of the DMA, streaming-store fill of broadcast results) are sized
+// from the CPUs this PROCESS may use, read once: the scheduler affinity mask, cut down to the cgroup CPU quota if one is set anywhere
+// between the process's own cgroup and the root (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- a GPU box hands every GPU
+// a share of the host (16 of 256 CPUs), which std::thread::hardware_concurrency() does not see.  The reference sizes its rayon pool
+// from the same information (`threads` = 0 -> every core the process has, src/anguelova.rs:467,524-525).  In a multi-device call
+// every device's pipeline runs on a host thread of its own and brings its own helpers: the budget is divided among them
+// (tl_sharers), so that 8 devices on a 16-CPU share start 16 helpers, not 64+.
+unsigned quota_from(const std::string& quota_file, const std::string& period_file) {
+  // v2: "max 100000" / "1600000 100000" in one file; v1: two files, quota -1 = none.  0 = no limit found here.
+  FILE* fh = fopen(quota_file.c_str(), "r");
+  if (!fh) return 0;
+  char a[64] = {0}, b[64] = {0};
+  const int got = fscanf(fh, "%63s %63s", a, b);
+  fclose(fh);
+  if (got < 1 || strcmp(a, "max") == 0) return 0;
+  double quota = atof(a), period = got >= 2 ? atof(b) : 0.0;
+  if (!period_file.empty()) {
+    FILE* ph = fopen(period_file.c_str(), "r");
+    if (!ph) return 0;
+    if (fscanf(ph, "%63s", b) == 1) period = atof(b);
+    fclose(ph);
+  }
+  if (quota <= 0.0 || period <= 0.0) return 0;
+  return (unsigned)std::max(1.0, std::floor(quota / period + 0.5));
+}
+
+// the cgroup path of this process for controller `want` ("" = the v2 unified hierarchy), from /proc/self/cgroup
+std::string own_cgroup(const char* want) {
+  FILE* fh = fopen("/proc/self/cgroup", "r");
+  if (!fh) return "";
+  char line[1024];
+  std::string found;
+  while (fgets(line, sizeof line, fh)) {
+    // hierarchy-ID:controller-list:path
+    char* c1 = strchr(line, ':');
+    char* c2 = c1 ? strchr(c1 + 1, ':') : nullptr;
+    if (!c2) continue;
+    std::string ctrl(c1 + 1, c2), path(c2 + 1);
+    while (!path.empty() && (path.back() == '\n' || path.back() == '\r')) path.pop_back();
+    const bool match = *want ? (("," + ctrl + ",").find(std::string(",") + want + ",") != std::string::npos) : ctrl.empty();
+    if (match) { found = path; break; }
+  }
+  fclose(fh);
+  return found;
+}
+
+// smallest CPU quota on the way from `leaf` (a cgroup path below `mount`) up to the mount point; 0 = none
+unsigned min_quota_upwards(const std::string& mount, std::string leaf, bool v2) {
+  unsigned best = 0;
+  for (;;) {
+    const std::string dir = mount + (leaf == "/" ? "" : leaf);
+    const unsigned q = v2 ? quota_from(dir + "/cpu.max", "") : quota_from(dir + "/cpu.cfs_quota_us", dir + "/cpu.cfs_period_us");
+    if (q && (!best || q < best)) best = q;
+    if (leaf.empty() || leaf == "/") break;
+    const size_t cut = leaf.find_last_of('/');
+    leaf = cut == 0 || cut == std::string::npos ? "/" : leaf.substr(0, cut);
+  }
+  return best;
+}
+
+unsigned detect_cpu_budget() {
+  unsigned n = std::max(1u, std::thread::hardware_concurrency());
+  cpu_set_t set;
+  CPU_ZERO(&set);
+  if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+  unsigned quota = min_quota_upwards("/sys/fs/cgroup", own_cgroup(""), true);  // v2 (inside a container the path may not exist below the mount: the root file still does)
+  if (!quota) quota = min_quota_upwards("/sys/fs/cgroup", "/", true);
+  for (const char* mount : {"/sys/fs/cgroup/cpu", "/sys/fs/cgroup/cpu,cpuacct"}) {  // v1
+    unsigned q = min_quota_upwards(mount, own_cgroup("cpu"), false);
+    if (!q) q = min_quota_upwards(mount, "/", false);
+    if (q && (!quota || q < quota)) quota = q;
+  }
+  return quota ? std::min(n, quota) : n;
+}
+
+unsigned host_cpu_budget() {
   static const unsigned v = [] {
-    const char* e = getenv("INFLX_PREFAULT_THREADS");  // tuning knob
+    const char* e = getenv("INFLX_HOST_THREADS");  // the budget by hand (tests, odd schedulers)
     const long n = e ? atol(e) : 0;
-    return (unsigned)(n > 0 ? n : 8);
+    return n > 0 ? (unsigned)n : detect_cpu_budget();
   }();
   return v;
+}
+
+// device pipelines that run at the same time as the calling thread's (set by run_parts for the duration of a part)
+thread_local unsigned tl_sharers = 1;
+
+// Helpers a host-result pipeline may start: {threads that make destination pages resident ahead of the DMA, threads that write a
+// broadcast result with streaming stores}, for a process that may use `cpus` CPUs and runs `sharers` device pipelines at once.
+//  * residency: half the budget, at most 8 (one thread touches ~10 GB/s of fresh pages; the DMA needs 50-57);
+//  * fill: memory-bound streaming stores gain from two threads per CPU of a quota'd share (hyperbolic 8192^2 on 16 CPUs: 16 threads
+//    15.2 ms, 32: 13.6, 64: 12.2) -- but only while nothing else competes for the share: with several devices at work every
+//    pipeline gets its plain share and nothing is oversubscribed.
+struct HelperPlan {
+  unsigned prefault, fill;
+};
+HelperPlan helper_plan(unsigned cpus, unsigned sharers) {
+  cpus = std::max(1u, cpus);
+  sharers = std::max(1u, sharers);
+  const unsigned share = std::max(1u, cpus / sharers);
+  HelperPlan h;
+  h.prefault = std::max(1u, std::min(8u, (share + 1) / 2));
+  h.fill = std::min(64u, sharers == 1 ? 2 * share : share);
+  return h;
+}
+
+unsigned prefault_threads() {
+  static const long forced = [] {
+    const char* e = getenv("INFLX_PREFAULT_THREADS");  // tuning knob: overrides the budget
+    return e ? atol(e) : 0L;
+  }();
+  return forced > 0 ? (unsigned)forced : helper_plan(host_cpu_budget(), tl_sharers).prefault;
+}
+
+unsigned host_fill_threads() {
+  static const long forced = [] {
+    const char* e = getenv("INFLX_HOST_FILL_THREADS");  // tuning knob: overrides the budget
+    return e ? atol(e) : 0L;
+  }();
+  return forced > 0 ? (unsigned)forced : helper_plan(host_cpu_budget(), tl_sharers).fill;
 }
 
 // Write-fault every page of a range without changing it: an atomic OR of 0 into one byte per page.  The
@@ -139,8 +254,7 @@ void prefault_range(char* begin, size_t bytes) {
 #ifdef MADV_HUGEPAGE
   (void)madvise(lo, (size_t)(hi - lo), MADV_HUGEPAGE);
 #endif
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), (size_t)(hi - lo) / (size_t(8) << 20) + 1);
+  const unsigned nthreads = (unsigned)std::min<size_t>(prefault_threads(), (size_t)(hi - lo) / (size_t(8) << 20) + 1);
   static const bool use_populate = [] {
     const char* e = getenv("INFLX_PREFAULT_MODE");  // tuning knob: "populate" or "touch"
     return e && strcmp(e, "populate") == 0;
@@ -208,6 +322,9 @@ struct inflx_model {
   // decided per call by evaluates_on_side_stream, read by launch_tiles: a tile sweep that is ONE launch builds its tables on
   // the caller's stream, in front of the tile kernel (no second stream, no event between the two)
   bool tables_on_callers_stream = false;
+  // inflx_sweep_flags of the call that holds the lock (INFLX_SWEEP_FORCE_TILE: every grid point through the tile kernels even where
+  // the model ignores a grid axis); set and cleared by the *_ex entry points
+  unsigned call_flags = 0;
   hipFunction_t tile_stats = nullptr, tile_stats_nostore = nullptr, rowvals_stats = nullptr;
   double* d_stats = nullptr;  // 18 x 8 bytes: min[6], max[6], count[6]
   // Row-broadcast path: per-row results [P][rows][replicas][8], double-buffered.  The per-row
@@ -356,7 +473,7 @@ int ensure_row_table(inflx_model* m, int b, size_t doubles) {
 
 // does this sweep take the two-launch row-broadcast path (per-row evaluation + store stream)?
 bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
-  if ((m->info.out_mask & 2u) != 0 || op == INFLX_OP_QDIF) return false;
+  if ((m->info.out_mask & 2u) != 0 || op == INFLX_OP_QDIF || (m->call_flags & INFLX_SWEEP_FORCE_TILE)) return false;
   const bool aos6 = kOpWidth[op] == 6 && layout == INFLX_AOS;
   (void)P;  // the path never depends on the number of parameter rows: they are batched (row_stream_plan)
   const bool planes = (layout == INFLX_SOA || kOpWidth[op] == 1) && N1 % 2 == 0;
@@ -366,7 +483,7 @@ bool takes_row_stream(const inflx_model* m, int op, int layout, size_t P, size_t
 // does this sweep take the two-launch column-broadcast path (row image + copy stream)?  No model value depends on
 // x[0], and an output row is a whole number of 16-byte units.
 bool takes_col_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
-  if ((m->info.out_mask & 3u) != 2u || op == INFLX_OP_QDIF) return false;
+  if ((m->info.out_mask & 3u) != 2u || op == INFLX_OP_QDIF || (m->call_flags & INFLX_SWEEP_FORCE_TILE)) return false;
   const size_t K = kOpWidth[op];
   const bool planes = layout == INFLX_SOA || K == 1;
   (void)P;  // batched in launch_col_stream
@@ -438,13 +555,20 @@ bool evaluates_on_side_stream(inflx_model* m, int op, int layout, size_t P, size
     m->tables_on_callers_stream = alone && P <= col_stream_batch(op, layout, P, N1);
     return !m->tables_on_callers_stream;
   }
-  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
+  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF && !(m->call_flags & INFLX_SWEEP_FORCE_TILE);
   if (row_uniform) return false;
   // tile path: tables, then tile kernel.  Several launches: the tables of launch k+1 are built on the side stream while the tile
   // kernel of launch k runs.  A single launch that nothing follows has nothing to overlap with, and the hop between two streams
   // (event record, wait, a second doorbell) is 10-15 us of the ~60 us a small sweep takes: it runs on the caller's stream alone.
   const TilePlan t = tile_plan(m, P, N1, row_count);
   m->tables_on_callers_stream = alone && P <= t.pbatch && row_count <= t.rows_per_launch;
+  // (experiments, scripts/tables_policy_probe.py: "same" = the tables of every single-launch sweep on the caller's stream, "side" = never)
+  static const int forced = [] {
+    const char* e = getenv("INFLX_EXPERIMENT_TABLES");
+    return !e ? 0 : (strcmp(e, "same") == 0 ? 1 : (strcmp(e, "side") == 0 ? 2 : 0));
+  }();
+  if (forced == 1) m->tables_on_callers_stream = P <= t.pbatch && row_count <= t.rows_per_launch;
+  if (forced == 2) m->tables_on_callers_stream = false;
   return !m->tables_on_callers_stream;
 }
 // ... and on which stream does the LAST kernel that reads them run?  The tile kernels read the parameter rows too
@@ -452,6 +576,34 @@ bool evaluates_on_side_stream(inflx_model* m, int op, int layout, size_t P, size
 bool last_reader_is_callers_stream(const inflx_model* m, int op, int layout, size_t P, size_t N1) {
   return !(takes_row_stream(m, op, layout, P, N1) || takes_col_stream(m, op, layout, P, N1));
 }
+
+// Has every kernel this handle enqueued earlier finished?  A sweep that arrives at an idle handle has nothing to overlap its
+// table evaluation with: it is enqueued as `alone` (tables in front of the tile kernel on the caller's stream, no second stream, no
+// event hop).  One that arrives while the previous sweep's kernels are still running keeps the side stream, where its tables are
+// evaluated under them.  (A user's lone call and the back-to-back calls of a scan both get the shorter of the two shapes.)
+bool handle_idle(inflx_model* m) {
+  bool idle = true;
+  for (int b = 0; b < 2 && idle; ++b) {
+    if (m->stage_used[b] && hipEventQuery(m->stage_free[b]) != hipSuccess) idle = false;
+    if (m->table_used[b] && hipEventQuery(m->table_free[b]) != hipSuccess) idle = false;
+  }
+  (void)hipGetLastError();  // hipErrorNotReady is an answer, not a failure
+  return idle;
+}
+
+// the inflx_sweep_flags of an *_ex call, for as long as it holds the handle's lock
+struct FlagScope {
+  inflx_model* m;
+  unsigned before;
+  FlagScope(inflx_model* m_, unsigned flags) : m(m_), before(m_ ? m_->call_flags : 0u) {
+    if (m) m->call_flags = flags;
+  }
+  ~FlagScope() {
+    if (m) m->call_flags = before;
+  }
+  FlagScope(const FlagScope&) = delete;
+  FlagScope& operator=(const FlagScope&) = delete;
+};
 
 // (in-pipeline timing of the dominant kernel, see inflx_model::probe) -- no-ops unless a probe is armed and has pairs left
 hipError_t probe_begin(inflx_model* m, hipStream_t s) {
@@ -647,7 +799,7 @@ int launch_tiles(inflx_model* m, int op, InflxSweepArgs a, const double* d_param
       a.stream_units = slab;
       // tables on the side stream, as soon as the tile kernel that read this buffer two launches ago is done ...
       if (m->stage_used[b]) HIP_TRY(hipStreamWaitEvent(tables, m->stage_free[b], 0));
-      const size_t tx = (std::max(slab, N1) + m->info.tile_cols - 1) / m->info.tile_cols;
+      const size_t tx = (slab + m->info.tile_cols - 1) / m->info.tile_cols + (N1 + m->info.tile_cols - 1) / m->info.tile_cols;  // row blocks, then column blocks
       HIP_TRY(hipModuleLaunchKernel(m->stage_tables, (unsigned)tx, (unsigned)pb, 1, m->info.tile_cols, 1, 1, 0, tables, params, nullptr));
       m->stage_turn++;
       // ... and the tile kernel on the caller's stream behind them
@@ -714,7 +866,7 @@ int launch_grid(inflx_model* m, int op, const double* d_params, size_t P, double
   if (takes_row_stream(m, op, layout, P, N1)) return launch_row_stream(m, op, a, d_params, P, d_out, N1, row_count, layout, s, what, d_stats);
   if (takes_col_stream(m, op, layout, P, N1)) return launch_col_stream(m, op, a, d_params, P, d_out, N1, row_count, layout, s, what, d_stats);
   // the flag sweep reads the basis vector, whose axis dependence the out_mask does not describe
-  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF;
+  const bool row_uniform = (m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF && !(m->call_flags & INFLX_SWEEP_FORCE_TILE);
   if (row_uniform) return launch_rows_fallback(m, op, a, P, N1, row_count, s);
   return launch_tiles(m, op, a, d_params, P, d_out, N1, row_count, s, d_stats);
 }
@@ -914,8 +1066,14 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
     fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_ops_on_values", artefact_path);
     return bail(INFLX_ERR_SYMBOL);
   }
+  // (experiment, scripts/tables_policy_probe.py: the side stream at the highest priority the device offers)
+  int side_priority = 0;
+  if (const char* e = getenv("INFLX_EXPERIMENT_SIDE_PRIORITY")) {
+    int least = 0, greatest = 0;
+    if (atoi(e) != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess) side_priority = greatest;
+  }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess ||
-      hipStreamCreateWithFlags(&m->side, hipStreamNonBlocking) != hipSuccess ||
+      hipStreamCreateWithPriority(&m->side, hipStreamNonBlocking, side_priority) != hipSuccess ||
       hipStreamCreateWithFlags(&m->copy_stream, hipStreamNonBlocking) != hipSuccess) {
     fail(INFLX_ERR_DEVICE, "could not create HIP streams");
     return bail(INFLX_ERR_DEVICE);
@@ -987,6 +1145,17 @@ uint32_t inflx_n_parameters(const inflx_model* m) { return m ? m->n_par : 0; }
 const char* inflx_model_name(const inflx_model* m) { return m ? m->name.c_str() : ""; }
 int inflx_device_of(const inflx_model* m) { return m ? m->device : -1; }
 
+int inflx_host_threads(unsigned devices_at_work, unsigned out[3]) {
+  if (!out) return fail(INFLX_ERR_ARG, "output array is NULL");
+  const unsigned saved = tl_sharers;
+  tl_sharers = std::max(1u, devices_at_work);
+  out[0] = host_cpu_budget();
+  out[1] = prefault_threads();  // (through the same functions the pipelines ask: environment overrides included)
+  out[2] = host_fill_threads();
+  tl_sharers = saved;
+  return INFLX_OK;
+}
+
 int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t* nc, uint32_t* out_mask) {
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   if (nu) *nu = m->info.n_uniform;
@@ -997,8 +1166,16 @@ int inflx_stage_info(const inflx_model* m, uint32_t* nu, uint32_t* nr, uint32_t*
 }
 
 int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t row_count, int layout, uint32_t plan[4]) {
-  if (!m || !plan) return fail(INFLX_ERR_ARG, "model handle / plan array is NULL");
+  return inflx_sweep_plan_ex(m, op, P, N1, row_count, layout, INFLX_SWEEP_DEFAULT, plan);
+}
+
+int inflx_sweep_plan_ex(const inflx_model* cm, int op, size_t P, size_t N1, size_t row_count, int layout, unsigned flags, uint32_t plan[4]) {
+  if (!cm || !plan) return fail(INFLX_ERR_ARG, "model handle / plan array is NULL");
   if (op < 0 || op >= INFLX_OP_COUNT) return fail(INFLX_ERR_ARG, "unknown sweep operation %d", op);
+  if (flags & ~(unsigned)INFLX_SWEEP_FORCE_TILE) return fail(INFLX_ERR_ARG, "unknown sweep flags 0x%x", flags);
+  inflx_model* m = const_cast<inflx_model*>(cm);  // (the flags live in the handle for the duration of the call)
+  INFLX_SERIALISE(m);
+  FlagScope scope(m, flags);
   plan[0] = plan[1] = plan[2] = plan[3] = 0;
   if (takes_row_stream(m, op, layout, P, N1)) {
     const RowStreamPlan r = row_stream_plan(m, op, layout, P, N1, row_count);
@@ -1008,7 +1185,7 @@ int inflx_sweep_plan(const inflx_model* m, int op, size_t P, size_t N1, size_t r
     plan[3] = (uint32_t)r.replicas;
   } else if (takes_col_stream(m, op, layout, P, N1)) {
     plan[0] = INFLX_PATH_COL_STREAM;
-  } else if ((m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF) {
+  } else if ((m->info.out_mask & 2u) == 0 && op != INFLX_OP_QDIF && !(m->call_flags & INFLX_SWEEP_FORCE_TILE)) {
     plan[0] = INFLX_PATH_ROWS;
   } else {
     plan[0] = INFLX_PATH_TILE;
@@ -1070,20 +1247,27 @@ int inflx_synchronize(inflx_model* m) {
 
 int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                        const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream) {
+  return inflx_sweep_device_ex(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream, INFLX_SWEEP_DEFAULT);
+}
+
+int inflx_sweep_device_ex(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
+                          const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream, unsigned flags) {
   INFLX_SERIALISE(m);
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
   if (!d_out || !ss) return fail(INFLX_ERR_ARG, "output / start_stop pointer is NULL");
   if (layout != INFLX_AOS && layout != INFLX_SOA) return fail(INFLX_ERR_ARG, "unknown layout %d", layout);
+  if (flags & ~(unsigned)INFLX_SWEEP_FORCE_TILE) return fail(INFLX_ERR_ARG, "unknown sweep flags 0x%x", flags);
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
   if (op == INFLX_OP_QDIF) return fail(INFLX_ERR_ARG, "the flag sweep has a byte result: use inflx_flag_quantum_dif");
   const size_t need = P * row_count * N1 * kOpBytes[op];
   if (d_out_bytes < need) return fail(INFLX_ERR_SHAPE, "output buffer has %zu bytes, the sweep writes %zu", d_out_bytes, need);
   HIP_TRY(hipSetDevice(m->device));
+  FlagScope scope(m, flags);
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
-  // the parameters are read by the kernel that evaluates the model: on the row-broadcast path that is
-  // the per-row evaluation on the side stream, otherwise the sweep kernel on the caller's stream
-  hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1, row_count) ? m->side : s;
+  // the parameters are read by the kernel that evaluates the model: the per-row / per-column evaluation or the stage tables -- on the
+  // side stream while an earlier sweep of this handle is still running (they overlap it), on the caller's stream at an idle handle
+  hipStream_t up = evaluates_on_side_stream(m, op, layout, P, N1, row_count, /*alone=*/handle_idle(m)) ? m->side : s;
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
@@ -1093,15 +1277,48 @@ int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                              const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream,
                              int repeats, int dominant_only, float* ms_per_launch) {
+  return inflx_sweep_device_timed_ex(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream, repeats, dominant_only,
+                                     INFLX_SWEEP_DEFAULT, ms_per_launch);
+}
+
+int inflx_sweep_device_timed_ex(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
+                                const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream,
+                                int repeats, int mode, unsigned flags, float* ms_per_launch) {
   INFLX_SERIALISE(m);
   if (repeats <= 0 || !ms_per_launch) return fail(INFLX_ERR_ARG, "repeats must be positive and ms_per_launch non-NULL");
+  if (mode < INFLX_TIME_BACK_TO_BACK || mode > INFLX_TIME_SINGLE_CALL) return fail(INFLX_ERR_ARG, "unknown timing mode %d", mode);
   // first call validates everything and uploads the parameters
-  int rc = inflx_sweep_device(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream);
+  int rc = inflx_sweep_device_ex(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream, flags);
   if (rc) return rc;
+  FlagScope scope(m, flags);
   hipStream_t s = stream ? static_cast<hipStream_t>(stream) : m->stream;
+  if (mode == INFLX_TIME_SINGLE_CALL) {
+    // what ONE call costs a caller whose handle is idle: every repetition waits until the device has nothing of this handle left,
+    // then brackets one whole inflx_sweep_device call -- tables (or per-row values) AND the sweep kernel -- with two events
+    float total = 0.f;
+    for (int k = 0; k < repeats; ++k) {
+      HIP_TRY(hipStreamSynchronize(m->side));
+      HIP_TRY(hipStreamSynchronize(s));
+      HIP_TRY(hipEventRecord(m->t0, s));
+      rc = inflx_sweep_device_ex(m, op, p, P, n_p, d_out, d_out_bytes, ss, N0, N1, row_begin, row_count, layout, stream, flags);
+      if (rc) return rc;
+      HIP_TRY(hipEventRecord(m->t1, s));
+      HIP_TRY(hipEventSynchronize(m->t1));
+      float one = 0.f;
+      HIP_TRY(hipEventElapsedTime(&one, m->t0, m->t1));
+      total += one;
+    }
+    HIP_TRY(hipStreamSynchronize(m->side));
+    *ms_per_launch = total / (float)repeats;
+    return INFLX_OK;
+  }
+  const int dominant_only = mode;
   hipStream_t reader = last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side;
   const double* d_params = m->pslot[m->pcur].dev;  // what the call above uploaded (or found in place)
   HIP_TRY(hipStreamSynchronize(s));
+  HIP_TRY(hipStreamSynchronize(m->side));
+  // the repetitions are enqueued back to back: the shape of a sweep that arrives while its predecessor runs (tables on the side stream)
+  (void)evaluates_on_side_stream(m, op, layout, P, N1, row_count, /*alone=*/false);
   // dominant_only == 2: the full sweeps, with an event pair around every dominant-kernel launch (at most 64 per sweep)
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pairs;
   struct Disarm {
@@ -1329,14 +1546,6 @@ bool host_fill_enabled() {
   }();
   return v;
 }
-unsigned host_fill_threads() {
-  static const unsigned v = [] {
-    const char* e = getenv("INFLX_HOST_FILL_THREADS");
-    const long n = e ? atol(e) : 0;
-    return (unsigned)(n > 0 ? n : 32);  // hyperbolic 8192^2 on a GPU box's host share (16 CPUs of 256): 4 threads 52 ms, 8: 26, 16: 15.2, 32: 13.6, 64: 12.2
-  }();
-  return v;
-}
 size_t host_fill_min_bytes() {
   static const size_t v = [] {
     const char* e = getenv("INFLX_HOST_FILL_MIN_MB");
@@ -1401,9 +1610,8 @@ void stream_copy(char* dst, const char* src, size_t bytes) {
 // Run fill(first, last) over [0, n) in contiguous blocks on up to host_fill_threads() threads (the calling thread takes one).
 template <typename F>
 void parallel_blocks(size_t n, size_t bytes_per_item, F fill) {
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   if (n == 0) return;
-  size_t nthreads = std::min<size_t>(std::min(host_fill_threads(), hw), n);
+  size_t nthreads = std::min<size_t>(host_fill_threads(), n);
   // a thread costs tens of microseconds to start: up to 8 threads get at least 4 MiB each, further ones 16 MiB (hyperbolic on a
   // GPU box's 16 CPUs: 1000^2 = 48 MB fastest with 8 threads, 2048^2 = 201 MB with 12 -- 32 take half as long again --, 8192^2 with 32)
   const size_t bytes = n * bytes_per_item;
@@ -1558,8 +1766,7 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
     std::vector<std::thread> pool;
     if (head_stripes < stripes.size()) {
       const size_t rest = stripes.size() - head_stripes;
-      const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-      const unsigned nthreads = (unsigned)std::min<size_t>(std::min(prefault_threads(), hw), rest);
+      const unsigned nthreads = (unsigned)std::min<size_t>(prefault_threads(), rest);
       // helpers are an optimisation: the copy is correct without them (the runtime faults pages in itself,
       // slowly), so a thread that cannot be created is simply not there
       try {
@@ -1910,7 +2117,10 @@ int run_parts(size_t n, F part) {
   std::vector<int> rcs(n, INFLX_OK);
   std::vector<std::string> msgs(n);
   auto body = [&](size_t k) {
+    const unsigned before = tl_sharers;
+    tl_sharers = (unsigned)n;  // n device pipelines share the process's host-thread budget for the duration of the call
     rcs[k] = part(k);
+    tl_sharers = before;
     if (rcs[k] != INFLX_OK) msgs[k] = g_last_error;  // thread-local: carried back by hand
   };
   std::vector<std::thread> pool;

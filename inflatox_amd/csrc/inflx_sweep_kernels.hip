@@ -789,15 +789,21 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
 // ================================================================================================
 // stage tables of the tile kernels: U per parameter row, R per grid row, C per grid column
 // ================================================================================================
-// grid: x = 256-thread blocks over max(slab rows, N1), y = parameter row.  Table layout (doubles) behind a.row_table:
+// grid: x = ceil(slab rows / 256) row blocks followed by ceil(N1 / 256) column blocks, y = parameter row.  Table layout
+// (doubles) behind a.row_table:
 //   U[P][kNU]  |  R[P][slab_rows][kNRs]  |  C[P][kNC][N1]      (kNRs = kNR rounded up to even)
 // (R row-major so that a tile's 32 rows are one contiguous block, C value-major so that the threads of a tile read
 // every value coalesced).  The slab is rows [stream_row0, stream_row0 + stream_units) relative to row_begin.
+// The kernel is a latency chain, not a throughput problem: U (one lane, dependent instructions), then a row's or a column's values
+// (one lane each).  Rows and columns therefore live in DIFFERENT workgroups -- the chain a lone call waits for in front of its tile
+// kernel is U + max(R, C), not U + R + C as it was while thread i evaluated row i and then column i.
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const InflxSweepArgs a) {
   const unsigned tid = threadIdx.x;
   const unsigned p = blockIdx.y;
-  const uint64_t idx = (uint64_t)blockIdx.x * kThreads + tid;
   const uint64_t slab_rows = a.stream_units;
+  const unsigned row_blocks = (unsigned)((slab_rows + kThreads - 1) / kThreads);
+  const bool rows = blockIdx.x < row_blocks;
+  const uint64_t idx = (uint64_t)(rows ? blockIdx.x : blockIdx.x - row_blocks) * kThreads + tid;
   double* utab = a.row_table + (uint64_t)p * kNU;
   double* rtab = a.row_table + (uint64_t)a.P * kNU + (uint64_t)p * slab_rows * kNRs;
   double* ctab = a.row_table + (uint64_t)a.P * (kNU + slab_rows * kNRs) + (uint64_t)p * kNC * a.N1;
@@ -819,11 +825,12 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const 
     for (int k = 0; k < kNU; ++k) utab[k] = U[k];
   }
 #endif
-  if (idx < slab_rows) {
-    const double x0 = inflx_coord(a.row_begin + a.stream_row0 + idx, a.dx0, a.x0a);
-    inflx_stage_row(x0, A, U, rtab + idx * kNRs);
-  }
-  if (idx < a.N1) {
+  if (rows) {
+    if (idx < slab_rows) {
+      const double x0 = inflx_coord(a.row_begin + a.stream_row0 + idx, a.dx0, a.x0a);
+      inflx_stage_row(x0, A, U, rtab + idx * kNRs);
+    }
+  } else if (idx < a.N1) {
     const double x1 = inflx_coord(idx, a.dx1, a.x1a);
     double C[kNC];
 #pragma unroll

@@ -168,8 +168,68 @@ int main() {
     Reporter off(&big, 1e9, false);
     CHECK(!off.active());
   }
+  // ---- one host-thread budget per process: helpers in flight never exceed the budget once several devices are at work
+  {
+    // 16 CPUs, 8 devices (a GPU box's share, a whole node's GPUs): at most 16 helpers in flight, whichever kind
+    const HelperPlan h = helper_plan(16, 8);
+    CHECK(8 * h.prefault <= 16 && 8 * h.fill <= 16 && h.prefault >= 1 && h.fill >= 1);
+    for (unsigned cpus : {1u, 2u, 3u, 8u, 16u, 64u, 256u})
+      for (unsigned dev : {1u, 2u, 3u, 4u, 8u}) {
+        const HelperPlan q = helper_plan(cpus, dev);
+        CHECK(q.prefault >= 1 && q.fill >= 1 && q.prefault <= 8 && q.fill <= 64);
+        if (dev > 1) CHECK(dev * q.fill <= std::max(cpus, dev) && dev * q.prefault <= std::max(cpus, dev));  // (a pipeline always has its own thread)
+        if (dev == 1) CHECK(q.fill <= 2 * cpus && q.prefault <= std::max(1u, (cpus + 1) / 2));
+      }
+    CHECK(helper_plan(16, 1).fill == 32 && helper_plan(16, 1).prefault == 8);  // the measured optimum of a 16-CPU share, one GPU
+    // quota files: v2 "max" = none, "1600000 100000" = 16; v1 quota -1 = none
+    char dir[] = "/tmp/inflx_quota_XXXXXX";
+    CHECK(mkdtemp(dir) != nullptr);
+    const std::string d = dir;
+    auto put = [&](const char* name, const char* text) {
+      FILE* fh = fopen((d + "/" + name).c_str(), "w");
+      fputs(text, fh);
+      fclose(fh);
+    };
+    put("cpu.max", "max 100000\n");
+    CHECK(quota_from(d + "/cpu.max", "") == 0);
+    put("cpu.max", "1600000 100000\n");
+    CHECK(quota_from(d + "/cpu.max", "") == 16);
+    put("cpu.max", "50000 100000\n");
+    CHECK(quota_from(d + "/cpu.max", "") == 1);  // half a CPU is still one thread
+    put("cpu.cfs_quota_us", "-1\n");
+    put("cpu.cfs_period_us", "100000\n");
+    CHECK(quota_from(d + "/cpu.cfs_quota_us", d + "/cpu.cfs_period_us") == 0);
+    put("cpu.cfs_quota_us", "800000\n");
+    CHECK(quota_from(d + "/cpu.cfs_quota_us", d + "/cpu.cfs_period_us") == 8);
+    // a limit on an intermediate ancestor is found on the way up: <d>/a/b/c (none) -> <d>/a (4 CPUs) -> <d> (8 via v1 files above: not looked at by the v2 walk)
+    CHECK(system(("mkdir -p " + d + "/a/b/c").c_str()) == 0);
+    put("a/cpu.max", "400000 100000\n");
+    put("a/b/cpu.max", "max 100000\n");
+    put("cpu.max", "1600000 100000\n");
+    CHECK(min_quota_upwards(d, "/a/b/c", true) == 4);
+    CHECK(min_quota_upwards(d, "/", true) == 16);
+    CHECK(min_quota_upwards(d, "/nonexistent/x", true) == 16);  // a path that does not exist below the mount: the root file still counts
+    CHECK(system(("rm -rf " + d).c_str()) == 0);
+    // the budget is at least one thread and the reported plan is the plan of the budget
+    unsigned out[3] = {0, 0, 0};
+    CHECK(inflx_host_threads(1, out) == INFLX_OK && out[0] >= 1 && out[1] >= 1 && out[2] >= 1);
+    unsigned out8[3];
+    CHECK(inflx_host_threads(8, out8) == INFLX_OK && out8[0] == out[0] && 8 * out8[2] <= std::max(out[0], 8u));
+    CHECK(inflx_host_threads(1, nullptr) == INFLX_ERR_ARG);
+    // run_parts hands every part the number of pipelines at work and restores the caller's view
+    std::atomic<unsigned> seen{0};
+    CHECK(run_parts(4, [&](size_t) -> int { seen += tl_sharers; return INFLX_OK; }) == INFLX_OK);
+    CHECK(seen == 16 && tl_sharers == 1);
+  }
   // ---- argument validation of the entry points that need no device
   CHECK(inflx_open(nullptr, 0, nullptr) == INFLX_ERR_ARG);
+  {
+    uint32_t plan[4];
+    float ms;
+    CHECK(inflx_sweep_plan_ex(nullptr, 0, 1, 1, 1, 0, INFLX_SWEEP_FORCE_TILE, plan) == INFLX_ERR_ARG);
+    CHECK(inflx_sweep_device_ex(nullptr, 0, nullptr, 1, 1, nullptr, 0, nullptr, 1, 1, 0, 1, 0, nullptr, INFLX_SWEEP_FORCE_TILE) == INFLX_ERR_ARG);
+    CHECK(inflx_sweep_device_timed_ex(nullptr, 0, nullptr, 1, 1, nullptr, 0, nullptr, 1, 1, 0, 1, 0, nullptr, 1, INFLX_TIME_SINGLE_CALL, 0, &ms) == INFLX_ERR_ARG);
+  }
   CHECK(inflx_sweep_host_multi(nullptr, 0, nullptr, 1, 1, nullptr, nullptr, 1, 1, 0, 0, 0) == INFLX_ERR_ARG);
   CHECK(inflx_multi_device_count(nullptr) == 0 && inflx_multi_handle(nullptr, 0) == nullptr);
   inflx_close(nullptr);

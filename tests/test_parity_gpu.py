@@ -557,7 +557,8 @@ def test_config4_all_eight_per_gpu_shares_hyperbolic_8192_x_512(gpu_lib):
     spec, art, lib = devlib("hyperbolic", gpu_lib)
     n, total, world = 8192, 512, 8
     axis = np.linspace(0.2, 2.0, total)
-    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, total // world, n, n) == {"path": "row_stream", "batch_rows": 4, "batches": 16, "replicas": 32}
+    plan = lib.sweep_plan(gpu_lib.OP_COMPLETE, total // world, n, n)
+    assert {k: plan[k] for k in ("path", "batch_rows", "batches", "replicas")} == {"path": "row_stream", "batch_rows": 4, "batches": 16, "replicas": 32}
     torch.cuda.empty_cache()
     free, _ = torch.cuda.mem_get_info()
     need = (total // world) * n * n * 48
@@ -1326,6 +1327,75 @@ def test_tile_launch_plan_of_typical_grids(gpu_lib):
     # more than 65535 full-height tiles of rows: several launches
     tall = lib.sweep_plan(gpu_lib.OP_COMPLETE, 1, 2, 2100001)
     assert tall["batches"] == 2 and tall["tile_rows"] == full
+
+
+def test_forced_tile_path_equals_the_row_stream_at_full_size(gpu_lib):
+    """BASELINE configs[1] evaluated per grid point (INFLX_SWEEP_FORCE_TILE: one lane per point through inflx_sweep_tile_complete, the
+    reference's own loop shape, src/anguelova.rs:526-539) returns the bits of the row-broadcast store stream the headline number is
+    measured on -- at the full 8192 x 8192, on the device, all 3.2 GB compared."""
+    import torch
+
+    spec, art, lib = devlib("hyperbolic", gpu_lib)
+    n = 8192
+    assert lib.sweep_plan(gpu_lib.OP_COMPLETE, 1, n, n)["path"] == "row_stream"
+    forced = lib.sweep_plan(gpu_lib.OP_COMPLETE, 1, n, n, force_tile=True)
+    assert forced["path"] == "tile" and forced["batches"] == 1, forced
+    a = torch.full((n, n, 6), -7.0, dtype=torch.float64, device="cuda")
+    b = torch.full((n, n, 6), -9.0, dtype=torch.float64, device="cuda")
+    lib.sweep_device(gpu_lib.OP_COMPLETE, spec.args, a.data_ptr(), a.numel() * 8, spec.extent, n, n)
+    lib.sweep_device(gpu_lib.OP_COMPLETE, spec.args, b.data_ptr(), b.numel() * 8, spec.extent, n, n, force_tile=True)
+    lib.synchronize()
+    torch.cuda.synchronize()
+    # bit for bit: compare the words, so that NaN == NaN (the consistency plane is all NaN for this model) and -0.0 != 0.0
+    assert torch.equal(a.view(torch.int64), b.view(torch.int64))
+    assert not torch.any(b == -9.0)
+    del a, b
+    torch.cuda.empty_cache()
+    # the flag changes the path, not the call: smaller and ragged shapes, planes, a single-value operation, a parameter batch, row slabs
+    rng = np.random.default_rng(11)
+    rows = np.asarray(spec.args, dtype=np.float64) * rng.uniform(0.8, 1.2, size=(3, len(spec.args)))
+    for n0, n1, P, rb, rc in ((96, 80, 1, 0, None), (70, 301, 2, 0, None), (129, 1000, 3, 17, 64), (33, 4098, 1, 0, None)):
+        for op, layout in ((gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_AOS), (gpu_lib.OP_COMPLETE, gpu_lib.LAYOUT_SOA), (gpu_lib.OP_EPSILON_V, gpu_lib.LAYOUT_AOS), (gpu_lib.OP_RAW, gpu_lib.LAYOUT_SOA)):
+            count = (n0 - rb) if rc is None else rc
+            k = gpu_lib.OP_WIDTH[op]
+            want = lib.sweep_host(op, rows[:P], spec.extent, n0, n1, row_begin=rb, row_count=rc, layout=layout)
+            buf = torch.full((P * count * n1 * k,), -3.0, dtype=torch.float64, device="cuda")
+            lib.sweep_device(op, rows[:P], buf.data_ptr(), buf.numel() * 8, spec.extent, n0, n1, row_begin=rb, row_count=rc, layout=layout, force_tile=True)
+            lib.synchronize()
+            got = buf.cpu().numpy().reshape(want.shape)
+            assert np.array_equal(got.view(np.int64), want.view(np.int64)), (n0, n1, P, rb, rc, op, layout)
+    # an unknown flag is refused
+    with pytest.raises(ValueError):
+        gpu_lib._check(gpu_lib.load_library().inflx_sweep_plan_ex(lib._h, gpu_lib.OP_COMPLETE, 1, 64, 64, gpu_lib.LAYOUT_AOS, 2, (gpu_lib.C.c_uint32 * 4)()))
+
+
+@pytest.mark.parametrize("name", ["hyperbolic", "doc", "egno"])
+def test_single_call_timing_brackets_the_whole_call(name, gpu_lib):
+    """INFLX_TIME_SINGLE_CALL: one sweep from an idle handle between two events -- tables (per-row values) AND the sweep kernel.  It
+    can be no shorter than the back-to-back figure less jitter (which hides the tables of sweep n+1 under sweep n), it leaves the
+    result of an ordinary sweep behind, and a lone call that follows is again enqueued as a lone call."""
+    import torch
+
+    spec, art, lib = devlib(name, gpu_lib)
+    n = 2048
+    want = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n, n)
+    buf = torch.full((n, n, 6), -5.0, dtype=torch.float64, device="cuda")
+    stream = torch.cuda.Stream()
+    kw = dict(stream=stream.cuda_stream)
+    back = min(lib.sweep_device_timed(gpu_lib.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, repeats=20, **kw) for _ in range(3))
+    single = min(lib.sweep_device_timed(gpu_lib.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, repeats=10, single_call=True, **kw) for _ in range(3))
+    assert single > 0.0 and back > 0.0
+    assert single >= 0.9 * back, (name, single, back)
+    assert single <= back + 0.25, (name, single, back)  # a quarter of a millisecond of tables in front of a 2048^2 sweep would be a regression
+    stream.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.int64), want.view(np.int64))
+    # idle handle -> the next plain call is a lone call; results unchanged
+    buf.fill_(-5.0)
+    lib.sweep_device(gpu_lib.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, **kw)
+    lib.sweep_device(gpu_lib.OP_COMPLETE, spec.args, buf.data_ptr(), buf.numel() * 8, spec.extent, n, n, **kw)  # ... and this one arrives while it runs
+    stream.synchronize()
+    lib.synchronize()
+    assert np.array_equal(buf.cpu().numpy().view(np.int64), want.view(np.int64))
 
 
 @pytest.mark.parametrize("name", ["doc", "d5"])
