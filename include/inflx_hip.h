@@ -77,6 +77,22 @@ int inflx_device_count(int* count);
 int inflx_open(const char* artefact_path, int device, inflx_model** out);
 void inflx_close(inflx_model* model);
 
+/*
+ * Kernel groups.  Every kernel that evaluates the model inlines the whole model, and a complete artefact holds ~45 of them: building
+ * all of it costs a heavy model several seconds of hipcc where the reference's one `zig cc` step takes about one
+ * (python/inflatox/compiler.py:568-598).  The artefact inflx_open takes is therefore the model's CORE object -- everything
+ * complete_analysis, the on-trajectory complete_analysis and the basis validation need -- or a complete one
+ * (Compiler(kernel_groups="all")); the kernels of the other operations live in one small code object per group:
+ *   "stats" (the fused summary), "consistency", "rapidturn", "epsilon_v", "raw", "qdif", "hesse", "values" (inflx_ops_on_values).
+ * An entry point that needs a group the handle lacks loads the file `<artefact>.<group>` if it exists (inflatox_amd builds the group
+ * and puts it there on first use) and fails with INFLX_ERR_SYMBOL otherwise.  inflx_attach loads a group object from any path; it must
+ * come from the same generated model and options as the core object (its MODEL_TAG global), else INFLX_ERR_VERSION.
+ * inflx_groups: bit mask of the groups loaded so far (bit k = the k-th name of: core, stats, values, consistency, rapidturn,
+ * epsilon_v, raw, qdif, hesse).
+ */
+int inflx_attach(inflx_model* model, const char* group_object_path);
+uint32_t inflx_groups(const inflx_model* model);
+
 /* InflatoxDylib::{n_fields,n_pars,name} (src/dylib.rs:285-301) */
 uint32_t inflx_n_fields(const inflx_model* model);
 uint32_t inflx_n_parameters(const inflx_model* model);

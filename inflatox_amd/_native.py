@@ -21,6 +21,10 @@ OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG, ERR_BASIS =
 
 OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
 OP_HESSE = 6  # v00, v01, v10, v11: the projected Hesse matrix with the reference's own v01 (INFLX_SWEEP_HESSE)
+OP_QDIF = 5
+# kernel group (inflatox_amd.compiler.KERNEL_GROUPS) of every operation: the artefact's core object holds complete_analysis, the others
+# are built and attached on first use
+OP_GROUP = {OP_COMPLETE: "core", OP_CONSISTENCY: "consistency", OP_RAPIDTURN: "rapidturn", OP_EPSILON_V: "epsilon_v", OP_RAW: "raw", OP_QDIF: "qdif", OP_HESSE: "hesse"}
 OP_WIDTH = {OP_COMPLETE: 6, OP_CONSISTENCY: 1, OP_RAPIDTURN: 1, OP_EPSILON_V: 1, OP_RAW: 5, OP_HESSE: 4}
 LAYOUT_AOS, LAYOUT_SOA = 0, 1
 SWEEP_DEFAULT, SWEEP_FORCE_TILE = 0, 1  # inflx_sweep_flags
@@ -36,6 +40,8 @@ SIGNATURES = {
     "inflx_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "inflx_open": (C.c_int, [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "inflx_close": (None, [C.c_void_p]),
+    "inflx_attach": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "inflx_groups": (C.c_uint32, [C.c_void_p]),
     "inflx_n_fields": (C.c_uint32, [C.c_void_p]),
     "inflx_n_parameters": (C.c_uint32, [C.c_void_p]),
     "inflx_model_name": (C.c_char_p, [C.c_void_p]),
@@ -211,6 +217,27 @@ def device_count() -> int:
     return n.value if rc == OK else 0
 
 
+def _ensure_group(lib, handles, artefact_path: str, group: str) -> None:
+    """Make the kernels of ``group`` available on every handle in ``handles``: nothing to do when they are loaded; otherwise the
+    artefact that owns ``artefact_path`` builds the group (one hipcc step on first use, ``CompilationArtifact.ensure_group``) and it
+    is attached.  An artefact from elsewhere (a bare file) is left to ``libinflx_hip.so``, which looks for ``<artefact>.<group>``
+    itself and says what is missing."""
+    from .compiler import KERNEL_GROUPS, artefact_for_path
+
+    bit = KERNEL_GROUPS[group]
+    pending = [h for h in handles if not (int(lib.inflx_groups(h)) & bit)]
+    if not pending:
+        return
+    art = artefact_for_path(artefact_path)
+    if art is None:
+        return
+    path = art.ensure_group(group)
+    if path is None:
+        return
+    for h in pending:
+        _check(lib.inflx_attach(h, os.fsencode(path)))
+
+
 class InflatoxDevLib:
     """An opened model artefact on one HIP device (counterpart of ``InflatoxPyDyLib``, lib.rs:104)."""
 
@@ -240,6 +267,15 @@ class InflatoxDevLib:
         except Exception:
             pass
 
+    def _need(self, group: str) -> None:
+        """The kernel group of the operation about to run (built and attached on first use; see ``_ensure_group``)."""
+        _ensure_group(self._lib, [self._h], self.path, group)
+
+    @property
+    def groups(self) -> int:
+        """Bit mask of the kernel groups loaded so far (``inflx_groups``; bits: ``inflatox_amd.compiler.KERNEL_GROUPS``)."""
+        return int(self._lib.inflx_groups(self._h))
+
     # ---- drop-ins for the #[pyfunction]s of src/anguelova.rs ---------------------------------
     def _grid(self, fn, p, out, start_stop, progress, threads, last_axis):
         p = _f64(p, "p").reshape(-1)
@@ -259,12 +295,15 @@ class InflatoxDevLib:
         self._grid(self._lib.inflx_complete_analysis, p, out, start_stop, progress, threads, 6)
 
     def consistency_only(self, p, out, start_stop, progress=False, threads=0):
+        self._need("consistency")
         self._grid(self._lib.inflx_consistency_only, p, out, start_stop, progress, threads, None)
 
     def consistency_rapidturn_only(self, p, out, start_stop, progress=False, threads=0):
+        self._need("rapidturn")
         self._grid(self._lib.inflx_consistency_rapidturn_only, p, out, start_stop, progress, threads, None)
 
     def epsilon_v_only(self, p, out, start_stop, progress=False, threads=0):
+        self._need("epsilon_v")
         self._grid(self._lib.inflx_epsilon_v_only, p, out, start_stop, progress, threads, None)
 
     def flag_quantum_dif(self, p, out, start_stop, progress=False, accuracy=1e-3):
@@ -275,6 +314,7 @@ class InflatoxDevLib:
             raise InflatoxShapeError(f"start_stop array should have 2 rows and as many columns as there are fields (got {ss.shape})")
         if out.dtype != np.bool_ or out.ndim != 2 or not out.flags.c_contiguous or not out.flags.writeable:
             raise ValueError("output array must be a writeable C-contiguous 2-D bool array")
+        self._need("qdif")
         _check(
             self._lib.inflx_flag_quantum_dif(
                 self._h, _ptr(p), p.size, out.view(np.uint8).ctypes.data_as(C.POINTER(C.c_uint8)), _ptr(ss), out.shape[0], out.shape[1], int(bool(progress)), float(accuracy)
@@ -287,6 +327,7 @@ class InflatoxDevLib:
         if x.ndim != 2 or x.shape[1] != 2:
             raise InflatoxShapeError(f"trajectory array should have shape (n,2) (got {x.shape})")
         k = OP_WIDTH[op]
+        self._need(OP_GROUP[op])
         from ._result_pool import result_array
 
         shape = (x.shape[0], k) if k > 1 else (x.shape[0],)
@@ -315,6 +356,7 @@ class InflatoxDevLib:
         if values.ndim != 2 or values.shape[1] != 5:
             raise InflatoxShapeError(f"values array should have shape (n,5) (got {values.shape})")
         out = np.zeros((values.shape[0], 9))
+        self._need("values")
         _check(self._lib.inflx_ops_on_values(self._h, _ptr(values), values.shape[0], _ptr(out), int(bool(ieee_only))))
         return out
 
@@ -352,6 +394,7 @@ class InflatoxDevLib:
         from ._result_pool import result_array
 
         out = result_array(shape)  # recycled page-resident memory where a dropped result of this size is at hand
+        self._need(OP_GROUP[op])
         _check(self._lib.inflx_sweep_host(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, layout))
         return out[0] if single else out
 
@@ -366,6 +409,7 @@ class InflatoxDevLib:
         from ._result_pool import result_array
 
         out = result_array((p2.shape[0], n_planes, row_count, N1))
+        self._need(OP_GROUP[op])
         _check(self._lib.inflx_sweep_host_planes(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], _ptr(out), _ptr(ss), N0, N1, row_begin, row_count, first_plane, n_planes))
         return out[0] if single else out
 
@@ -376,6 +420,7 @@ class InflatoxDevLib:
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         row_count = N0 - row_begin if row_count is None else row_count
+        self._need(OP_GROUP[op])
         _check(
             self._lib.inflx_sweep_device_ex(
                 self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream),
@@ -395,6 +440,7 @@ class InflatoxDevLib:
         row_count = N0 - row_begin if row_count is None else row_count
         mode = TIME_SINGLE_CALL if single_call else (TIME_IN_PIPELINE if in_pipeline else (TIME_DOMINANT_ONLY if dominant_only else TIME_BACK_TO_BACK))
         ms = C.c_float(0.0)
+        self._need(OP_GROUP[op])
         _check(
             self._lib.inflx_sweep_device_timed_ex(
                 self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, layout, C.c_void_p(stream), repeats, mode,
@@ -411,6 +457,7 @@ class InflatoxDevLib:
         ss = _f64(start_stop, "start_stop").reshape(-1)
         row_count = N0 - row_begin if row_count is None else row_count
         out = Summary()
+        self._need("stats")
         _check(
             self._lib.inflx_sweep_device_stats(
                 self._h, _ptr(p2), p2.shape[0], p2.shape[1], C.c_void_p(d_out_ptr), d_out_bytes, _ptr(ss), N0, N1, row_begin, row_count, C.c_void_p(stream), C.byref(out)
@@ -488,6 +535,10 @@ class InflatoxMultiLib:
         except Exception:
             pass
 
+    def _need(self, group: str) -> None:
+        handles = [self._lib.inflx_multi_handle(self._h, k) for k in range(self.n_devices)]
+        _ensure_group(self._lib, handles, self.path, group)
+
     def complete_analysis(self, p, out, start_stop, progress=False, threads=0):
         """``libinflx_rs.complete_analysis(lib, p, out, start_stop, progress, threads)`` (anguelova.rs:458) on the handle's
         devices: ``threads`` = 0 uses all of them, k at most k."""
@@ -520,6 +571,7 @@ class InflatoxMultiLib:
             out = result_array(shape)
         elif out.shape != shape or out.dtype != np.float64 or not out.flags.c_contiguous or not out.flags.writeable:
             raise ValueError(f"out must be a writeable C-contiguous float64 array of shape {shape}")
+        self._need(OP_GROUP[op])
         _check(self._lib.inflx_sweep_host_multi(self._h, op, _ptr(p2), P, p2.shape[1], _ptr(out), _ptr(ss), N0, N1, layout, int(bool(progress)), int(max_devices)))
         return out[0] if single else out
 
@@ -533,6 +585,7 @@ class InflatoxMultiLib:
         ptrs = (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in d_out_ptrs])
         sizes = (_SIZE * n)(*[int(v) for v in d_out_bytes])
         st = None if streams is None else (C.c_void_p * n)(*[C.c_void_p(int(v)) for v in streams])
+        self._need(OP_GROUP[op])
         _check(self._lib.inflx_sweep_device_multi(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, sizes, _ptr(ss), N0, N1, layout, st))
 
     def sweep_allgather(self, op, p, d_full_ptrs, d_full_bytes, start_stop, N0, N1, gather="peer_push"):
@@ -544,7 +597,10 @@ class InflatoxMultiLib:
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         ptrs = (C.c_void_p * self.n_devices)(*[C.c_void_p(int(v)) for v in d_full_ptrs])
+        if gather not in ("peer_push", "rccl"):
+            raise ValueError(f"unknown gather {gather!r}: choose 'peer_push' or 'rccl'")
         mode = {"peer_push": GATHER_PEER_PUSH, "rccl": GATHER_RCCL}[gather]
+        self._need(OP_GROUP[op])
         _check(self._lib.inflx_sweep_allgather_multi_ex(self._h, op, _ptr(p2), p2.shape[0], p2.shape[1], ptrs, int(d_full_bytes), _ptr(ss), N0, N1, mode))
 
     def sweep_stats(self, p, start_stop, N0, N1, max_devices=0) -> dict:
@@ -552,6 +608,7 @@ class InflatoxMultiLib:
         p2 = p2.reshape(1, -1) if p2.ndim == 1 else p2
         ss = _f64(start_stop, "start_stop").reshape(-1)
         out = Summary()
+        self._need("stats")
         _check(self._lib.inflx_sweep_stats_multi(self._h, _ptr(p2), p2.shape[0], p2.shape[1], _ptr(ss), N0, N1, int(max_devices), C.byref(out)))
         return {"min": np.array(out.min[:]), "max": np.array(out.max[:]), "count": np.array(out.count[:], dtype=np.uint64)}
 

@@ -31,6 +31,7 @@ import shutil
 import subprocess
 import sys
 import tempfile
+import weakref
 
 import numpy as np
 import sympy
@@ -41,6 +42,23 @@ from .symbolic import InflationModel
 from .version import __abi_version__, __version__
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+
+# Kernel groups of a model's code objects (csrc/inflx_kernel_abi.h INFLX_GROUP_*): name -> bit.  ``Compiler.compile()`` builds the
+# CORE object -- everything complete_analysis needs -- in one hipcc step, like the reference's one ``zig cc`` step
+# (python/inflatox/compiler.py:568-598); the group of every other operation is built when first used
+# (``CompilationArtifact.ensure_group``) and loaded beside the core object (``inflx_attach``).
+KERNEL_GROUPS = {"core": 1, "stats": 2, "values": 4, "consistency": 8, "rapidturn": 16, "epsilon_v": 32, "raw": 64, "qdif": 128, "hesse": 256}
+ALL_GROUPS = 511
+# op number (csrc/inflx_kernel_abi.h InflxOp) -> group name
+GROUP_OF_OP = {0: "core", 1: "consistency", 2: "rapidturn", 3: "epsilon_v", 4: "raw", 5: "qdif", 6: "hesse"}
+
+# artefacts of this process by the path of their core object: how _native finds the artefact that can build a missing group
+_ARTEFACTS: "weakref.WeakValueDictionary[str, CompilationArtifact]" = weakref.WeakValueDictionary()
+
+
+def artefact_for_path(path: str):
+    """The live :class:`CompilationArtifact` whose core object is ``path`` (None: the file came from somewhere else)."""
+    return _ARTEFACTS.get(os.path.abspath(path))
 
 # The reference's generated C defines the <math.h> M_* constants itself, truncated to 12
 # significant digits, whenever the header does not provide them -- and under the strict
@@ -196,6 +214,39 @@ class CompilationArtifact:
         self.stage_info = stage_info or {}
         self.header_path = header_path
         self._recipe = None  # (model, Compiler keyword arguments): set by Compiler.compile, used by profile_guided
+        self.kernel_groups = ALL_GROUPS  # groups inside shared_object_path (Compiler.compile sets what it built)
+        self._build = None  # (header text, final hipcc options, content tag): what ensure_group compiles a further group from
+        self._group_paths = {}
+        _ARTEFACTS[os.path.abspath(shared_object_path)] = self
+
+    def ensure_group(self, group: str) -> str | None:
+        """Extension: make the kernel group ``group`` (a key of ``KERNEL_GROUPS``) of this model available and return the path of its
+        code object -- ``shared_object_path + "." + group``, the place ``libinflx_hip.so`` looks for it -- or None when the core
+        object carries it already.  Built by one hipcc step from the very header and options of the core object on first use (cached in
+        the content-addressed cache like everything else); what :class:`inflatox_amd._native.InflatoxDevLib` calls before an operation
+        other than complete_analysis."""
+        bit = KERNEL_GROUPS[group]
+        if self.kernel_groups & bit:
+            return None
+        path = self._group_paths.get(group)
+        if path is None or not os.path.exists(path):
+            if self._build is None:
+                raise ValueError(f"this artefact does not know how it was compiled: kernel group {group!r} cannot be built (not made by Compiler.compile)")
+            header_text, options, tag = self._build
+            cached, log, code = _build_code_object(header_text, options, tag, bit)
+            if code != 0:
+                print(log.decode("utf-8", "replace"))
+                raise Exception(f"hipcc compiler error while building kernel group {group!r} (see previous output)")
+            path = self.shared_object_path + "." + group
+            tmp = path + f".{os.getpid()}.tmp"
+            shutil.copyfile(cached, tmp)
+            os.replace(tmp, path)
+            self._group_paths[group] = path
+        return path
+
+    def ensure_all_groups(self) -> list[str]:
+        """Extension: every group beside the core object (what a C client of ``libinflx_hip.so`` wants in place before it starts)."""
+        return [p for p in (self.ensure_group(g) for g in KERNEL_GROUPS) if p]
 
     def profile_guided(self, args, extent, silent: bool = True) -> "CompilationArtifact":
         """Extension: the profile-guided build of the same model -- ``Compiler(model, ..., regroup="auto", sample=(args,
@@ -213,10 +264,11 @@ class CompilationArtifact:
 
     def __del__(self):
         if getattr(self, "auto_cleanup", False):
-            try:
-                os.remove(self.shared_object_path)
-            except OSError:
-                pass
+            for path in [self.shared_object_path, *getattr(self, "_group_paths", {}).values()]:
+                try:
+                    os.remove(path)
+                except OSError:
+                    pass
 
     def lookup_symbol(self, symbol):
         name = self.symbol_printer._print_Symbol(symbol)
@@ -272,6 +324,31 @@ def hipcc_path() -> str:
     return cand
 
 
+def _build_code_object(header_text: str, options: list[str], tag: str, groups: int):
+    """One hipcc step: the kernels of ``groups`` for the model ``header_text`` under ``options`` into the content-addressed cache
+    (``<tag>.hsaco`` for an object that holds the core group, ``<tag>.g<mask>.hsaco`` for the others; ``tag`` = SHA-256 over header,
+    kernel sources and options).  Returns (path, compiler output, exit code)."""
+    cache = _cache_dir()
+    kernel_src = os.path.join(_CSRC, "inflx_sweep_kernels.hip")
+    header_path = os.path.join(cache, f"{tag}.h")
+    cached = os.path.join(cache, f"{tag}.hsaco" if groups == KERNEL_GROUPS["core"] else f"{tag}.g{groups}.hsaco")
+    log, code = b"", 0
+    if not os.path.exists(cached):
+        # several ranks may compile the same model at once: every file appears atomically
+        if not os.path.exists(header_path):
+            tmp_hdr = header_path + f".{os.getpid()}.tmp"
+            with open(tmp_hdr, "w") as fh:
+                fh.write(header_text)
+            os.replace(tmp_hdr, header_path)
+        tmp_out = cached + f".{os.getpid()}.tmp"
+        cmd = [hipcc_path(), *options, f"-DINFLX_KERNEL_GROUPS={groups}u", f'-DINFLX_MODEL_TAG="{tag}"', f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
+        proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+        log, code = proc.stdout, proc.returncode
+        if code == 0:
+            os.replace(tmp_out, cached)
+    return cached, log, code
+
+
 class Compiler:
     """Turns an :class:`InflationModel` into a gfx950 code object holding the sweep kernels.
 
@@ -324,6 +401,12 @@ class Compiler:
       far inside the 1e-10 bar, and towards the exact value -- but the results are then no longer the composition bit for
       bit, which is why the default build does not take it; a wavefront all of whose points qualify skips the ~55
       instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
+
+    * ``kernel_groups`` (default ``"core"``): which kernel groups ``compile()`` builds into the artefact's code object.  ``"core"``: what
+      ``complete_analysis`` (grid and on-trajectory) and the basis validation need -- ONE hipcc step of 1-2.5 s (D5: 2.2 s), like the
+      reference's one ``zig cc`` step; every other operation's group (``KERNEL_GROUPS``) is built when first used, 1.5-2.5 s each
+      (``CompilationArtifact.ensure_group``).  ``"all"``: a complete artefact in one step (D5: 5.4 s), for a C client of
+      ``libinflx_hip.so`` that wants a single file; or an iterable of group names (the core group is always included).
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order; spherical ones of integer
@@ -393,13 +476,26 @@ class Compiler:
         share_reciprocals: bool = False,
         sample=None,
         quick_sqrt: bool | None = None,
+        kernel_groups="core",
     ):
         # what CompilationArtifact.profile_guided needs to compile the same model again with a measured re-association
         self._init_kwargs = dict(output_path=None, cleanup=cleanup, silent=silent, link_gsl=link_gsl, cse=cse, max_cses=max_cses, compiler_flags=compiler_flags,
-                                 staged=staged, exact_constants=exact_constants, hoist_reciprocals=hoist_reciprocals, share_reciprocals=share_reciprocals, quick_sqrt=quick_sqrt)
+                                 staged=staged, exact_constants=exact_constants, hoist_reciprocals=hoist_reciprocals, share_reciprocals=share_reciprocals, quick_sqrt=quick_sqrt,
+                                 kernel_groups=kernel_groups)
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
         self.gsl = bool(link_gsl)
+        if isinstance(kernel_groups, str):
+            if kernel_groups not in ("core", "all"):
+                raise ValueError('kernel_groups must be "core", "all" or an iterable of group names')
+            self.kernel_groups = ALL_GROUPS if kernel_groups == "all" else KERNEL_GROUPS["core"]
+        else:
+            unknown = [g for g in kernel_groups if g not in KERNEL_GROUPS]
+            if unknown:
+                raise ValueError(f"kernel_groups: unknown group(s) {unknown}; choose from {sorted(KERNEL_GROUPS)}")
+            self.kernel_groups = KERNEL_GROUPS["core"]
+            for g in kernel_groups:
+                self.kernel_groups |= KERNEL_GROUPS[g]
         if model.dim != 2:
             raise Exception("the HIP sweep back-end supports two-field models only")
         self.symbolic_out = model
@@ -573,7 +669,7 @@ class Compiler:
                 regroup=self.regroup,
                 hoist_reciprocals=hoist,
                 share_point_reciprocals=self.share_reciprocals,
-                quick_sqrt=bool(hoist) if self.quick_sqrt is None else bool(self.quick_sqrt),
+                quick_sqrt=(hoist is True or hoist == 1) if self.quick_sqrt is None else bool(self.quick_sqrt),
             )
 
         if self.hoist_reciprocals is None:
@@ -628,22 +724,9 @@ class Compiler:
             hh = h.copy()
             hh.update(" ".join(options).encode())
             tag = hh.hexdigest()[:20]
-            cached = os.path.join(cache, f"{tag}.hsaco")
-            header_path = os.path.join(cache, f"{tag}.h")
-            log, code = b"", 0
-            if not os.path.exists(cached):
-                # several ranks may compile the same model at once: every file appears atomically
-                tmp_hdr = header_path + f".{os.getpid()}.tmp"
-                with open(tmp_hdr, "w") as fh:
-                    fh.write(header_text)
-                os.replace(tmp_hdr, header_path)
-                tmp_out = cached + f".{os.getpid()}.tmp"
-                cmd = [hipcc_path(), *options, f"-I{_CSRC}", f'-DINFLX_MODEL_HEADER="{header_path}"', kernel_src, "-o", tmp_out]
-                proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
-                log, code = proc.stdout, proc.returncode
-                if code == 0:
-                    os.replace(tmp_out, cached)
-            return cached, header_path, log, code
+            # what compile() builds: the core group (one hipcc step) unless the caller asked for more in the same object
+            cached, log, code = _build_code_object(header_text, options, tag, self.kernel_groups)
+            return cached, os.path.join(cache, f"{tag}.h"), log, code, list(options), tag
 
         if any(o.startswith("-DINFLX_MIN_WAVES") for o in opts):
             return build(opts)
@@ -652,6 +735,8 @@ class Compiler:
         # below that anyway, a heavy one (D5: 194) is asked to fit (__launch_bounds__(256, 3)) and accepted when the
         # register allocator gets there with a handful of spilled values (D5: 13 registers, 3 scratch accesses per grid
         # row, 15.1 -> 14.3 ms for 4096^2 x 32); a model that would spill in earnest keeps two (the choice is cached).
+        # The decision is read off the object compile() builds anyway (it holds inflx_sweep_tile_complete); the groups built later
+        # follow it.
         three = opts + ["-DINFLX_MIN_WAVES=3"]
         hh = h.copy()
         hh.update(" ".join(three).encode())
@@ -673,7 +758,7 @@ class Compiler:
         if not self.silent:
             print("Compiling model...")
         header = self._generate_hip_header()
-        cached, header_path, log, code = self._hipcc_compile(header)
+        cached, header_path, log, code, options, tag = self._hipcc_compile(header)
         if code != 0:
             print(log.decode("utf-8", "replace"))
             print(f'Problematic source file located at: "{header_path}"')
@@ -699,4 +784,6 @@ class Compiler:
             header_path=header_path,
         )
         art._recipe = (self.symbolic_out, dict(self._init_kwargs))
+        art.kernel_groups = self.kernel_groups
+        art._build = (header, options, tag)
         return art

@@ -103,6 +103,30 @@ INFLX_FN double inflx_div_by_hoisted(double a, double b, double y, bool& ok) {
   return q;
 }
 
+// The same three operations for models whose point stage is NOT kept twice (Compiler(hoist_reciprocals="inline"): EGNO -- a dozen
+// quotients by row / parameter values, too few to pay for a second copy of the stage and the `ok` bookkeeping of the row redo, which
+// cost it 20 registers and the third wavefront per SIMD).  The quotient checks itself with the one comparison above; a wavefront in
+// which any lane fails it -- NaN / infinite / zero / tiny operands, a reciprocal that inflx_recip refused -- divides THOSE lanes
+// with the compiler's IEEE sequence on the spot.  The branch is wave-uniform (a ballot), so the eleven instructions of the division
+// are off the hot path and never if-converted into it; the value is RN(a/b) either way.
+#ifndef INFLX_HOST_TWIN
+INFLX_FN double inflx_div_by_hoisted_inline(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  double q = __builtin_fma(r, y, q0);
+  const bool regular = __builtin_fabs(q) >= 0x1p-400;
+  if (__builtin_expect(__builtin_amdgcn_ballot_w64(!regular) != 0, 0)) q = regular ? q : a / b;
+  return q;
+}
+#else
+INFLX_FN double inflx_div_by_hoisted_inline(double a, double b, double y) {
+  const double q0 = a * y;
+  const double r = __builtin_fma(-b, q0, a);
+  const double q = __builtin_fma(r, y, q0);
+  return __builtin_fabs(q) >= 0x1p-400 ? q : a / b;
+}
+#endif
+
 // ---- quotients of the point stage that share a PER-POINT denominator ---------------------------------------
 // (D5 divides four times by r_44*p_5 at every grid point.)  The compiler's IEEE division is: two v_div_scale, v_rcp_f64
 // and two Newton steps on the reciprocal (5 instructions), then q0 = a*y, r = fma(-b, q0, a), q = fma(r, y, q0) (v_div_fmas

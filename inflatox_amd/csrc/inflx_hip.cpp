@@ -343,6 +343,11 @@ struct inflx_model {
   size_t probe_used = 0;
   bool probe_overflow = false;  // more dominant-kernel launches than event pairs: the timing would be partial
   InflxKernelInfo info = {};
+  // kernel groups (inflx_kernel_abi.h): the artefact is the core object; the groups of the other operations are loaded beside it on
+  // first use -- inflx_attach, or the file `<artefact>.<group>` if it exists (need_groups)
+  uint32_t groups = 0;
+  std::vector<hipModule_t> attached;
+  std::string tag;  // MODEL_TAG of the core object: what an attached group must carry too
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
   std::string name, path;
@@ -445,8 +450,106 @@ int release_params_after(inflx_model* m, hipStream_t reader, int rc) {
   return rc;
 }
 
+// ---- kernel groups ----------------------------------------------------------------------------------------------------------
+const char* const kGroupNames[9] = {"core", "stats", "values", "consistency", "rapidturn", "epsilon_v", "raw", "qdif", "hesse"};
+uint32_t group_of_op(int op) { return INFLX_GROUP_OF_OP(op); }
+
+// the kernels of the groups `mask` names, out of `module`
+int resolve_group_kernels(inflx_model* m, hipModule_t module, uint32_t mask, const char* path) {
+  auto get = [&](hipFunction_t* slot, const std::string& name) -> int {
+    if (hipModuleGetFunction(slot, module, name.c_str()) != hipSuccess) {
+      *slot = nullptr;
+      return fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s", path, name.c_str());
+    }
+    return INFLX_OK;
+  };
+  int rc;
+  for (int op = 0; op < INFLX_OP_COUNT; ++op) {
+    if (!(mask & group_of_op(op))) continue;
+    const std::string nm = kOpNames[op];
+    if ((rc = get(&m->tile[op], "inflx_sweep_tile_" + nm)) || (rc = get(&m->rows[op], "inflx_sweep_rows_" + nm)) || (rc = get(&m->traj[op], "inflx_sweep_traj_" + nm)) ||
+        (rc = get(&m->rowvals[op], "inflx_sweep_rowvals_" + nm)) || (rc = get(&m->colvals[op], "inflx_sweep_colvals_" + nm)))
+      return rc;
+  }
+  if (mask & INFLX_GROUP_CORE) {
+    if ((rc = get(&m->rowstream6, "inflx_sweep_rowstream6")) || (rc = get(&m->rowstream_planes, "inflx_sweep_rowstream_planes")) || (rc = get(&m->colstream, "inflx_sweep_colstream")) ||
+        (rc = get(&m->stage_tables, "inflx_stage_tables")) || (rc = get(&m->basis_points, "inflx_basis_points")))
+      return rc;
+  }
+  if (mask & INFLX_GROUP_STATS) {
+    if ((rc = get(&m->tile_stats, "inflx_sweep_tile_complete_stats")) || (rc = get(&m->tile_stats_nostore, "inflx_sweep_tile_complete_stats_nostore")) ||
+        (rc = get(&m->rowvals_stats, "inflx_sweep_rowvals_complete_stats")) || (rc = get(&m->colvals_stats, "inflx_sweep_colvals_complete_stats")))
+      return rc;
+  }
+  if (mask & INFLX_GROUP_VALUES) {
+    if ((rc = get(&m->ops_on_values, "inflx_ops_on_values"))) return rc;
+  }
+  return INFLX_OK;
+}
+
+template <typename T>
+int read_global_of(hipModule_t module, const char* path, const char* sym, T* dst, size_t bytes, bool exact) {
+  hipDeviceptr_t dptr = nullptr;
+  size_t size = 0;
+  if (hipModuleGetGlobal(&dptr, &size, module, sym) != hipSuccess) return fail(INFLX_ERR_SYMBOL, "artefact %s lacks symbol %s", path, sym);
+  if (exact ? size != bytes : size > bytes) return fail(INFLX_ERR_SYMBOL, "symbol %s in %s has %zu bytes, expected %s%zu", sym, path, size, exact ? "" : "<= ", bytes);
+  HIP_TRY(hipMemcpy(dst, dptr, size, hipMemcpyDeviceToHost));
+  return INFLX_OK;
+}
+
+// Load the code object at `path` beside the core object of `m`: it must be built from the same generated model with the same options
+// (MODEL_TAG) for the same kernel ABI; the kernels of the groups it carries and the handle lacks become available.
+int attach_object(inflx_model* m, const char* path) {
+  hipModule_t module = nullptr;
+  hipError_t e = hipModuleLoad(&module, path);
+  if (e != hipSuccess) return fail(INFLX_ERR_IO, "could not load %s as a gfx950 code object: %s", path, hipGetErrorString(e));
+  auto bail = [&](int code) {
+    const std::string first = g_last_error;
+    (void)hipModuleUnload(module);
+    g_last_error = first;
+    return code;
+  };
+  uint16_t version[3] = {};
+  InflxKernelInfo info = {};
+  uint32_t groups = 0;
+  char tag[128] = {0};
+  int rc;
+  if ((rc = read_global_of(module, path, "VERSION", version, sizeof version, true)) || (rc = read_global_of(module, path, "INFLX_KERNEL_INFO", &info, sizeof info, true)) ||
+      (rc = read_global_of(module, path, "INFLX_GROUPS", &groups, sizeof groups, true)) || (rc = read_global_of(module, path, "MODEL_TAG", tag, sizeof tag - 1, false)))
+    return bail(rc);
+  if (version[0] != m->version[0] || version[1] != m->version[1] || memcmp(&info, &m->info, sizeof info) != 0 || m->tag != tag)
+    return bail(fail(INFLX_ERR_VERSION, "%s does not belong to artefact %s: built from another model, with other options or for another kernel ABI (tag \"%s\", expected \"%s\")",
+                     path, m->path.c_str(), tag, m->tag.c_str()));
+  const uint32_t fresh = groups & ~m->groups;
+  if ((rc = resolve_group_kernels(m, module, fresh, path))) return bail(rc);
+  m->attached.push_back(module);
+  m->groups |= fresh;
+  return INFLX_OK;
+}
+
+// Make the kernels of the groups in `mask` available: those the handle lacks are looked for next to the artefact, as
+// `<artefact>.<group>` (where inflatox_amd puts a group when it builds one; a C client may put them there too).
+int need_groups(inflx_model* m, uint32_t mask) {
+  uint32_t missing = mask & ~m->groups & INFLX_GROUP_ALL;
+  for (int b = 0; missing && b < 9; ++b) {
+    const uint32_t bit = 1u << b;
+    if (!(missing & bit)) continue;
+    const std::string side = m->path + "." + kGroupNames[b];
+    FILE* fh = fopen(side.c_str(), "rb");
+    if (!fh)
+      return fail(INFLX_ERR_SYMBOL, "the kernels of group \"%s\" are not part of %s and no %s exists: build that group (inflatox_amd does on first use; "
+                  "Compiler(kernel_groups=\"all\") builds a complete artefact) and pass it to inflx_attach", kGroupNames[b], m->path.c_str(), side.c_str());
+    fclose(fh);
+    HIP_TRY(hipSetDevice(m->device));
+    const int rc = attach_object(m, side.c_str());
+    if (rc) return rc;
+    missing = mask & ~m->groups & INFLX_GROUP_ALL;
+  }
+  return INFLX_OK;
+}
+
 // validate_lib + validiate_p (src/anguelova.rs:55-79) and the Hesse2D guard (hesse_bindings.rs:203)
-int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p) {
+int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p, bool kernels = true) {
   if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
   if (op < 0 || op >= INFLX_OP_COUNT) return fail(INFLX_ERR_ARG, "unknown sweep operation %d", op);
   if (m->dim != 2)
@@ -456,6 +559,12 @@ int validate(const inflx_model* m, int op, const double* p, size_t P, size_t n_p
     return fail(INFLX_ERR_SHAPE, "model \"%s\" has %u paramters (got %zu)", m->name.c_str(), m->n_par, n_p);
   if (!p && n_p) return fail(INFLX_ERR_ARG, "parameter array is NULL");
   if (P == 0) return fail(INFLX_ERR_SHAPE, "parameter array has no rows");
+  // the kernels of this operation (loaded on first use when the artefact is a core object)
+  if (kernels && (m->groups & group_of_op(op)) == 0) {
+    inflx_model* mm = const_cast<inflx_model*>(m);
+    INFLX_SERIALISE(mm);
+    return need_groups(mm, group_of_op(op));
+  }
   return INFLX_OK;
 }
 
@@ -1026,45 +1135,21 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
          INFLX_KERNEL_ABI);
     return bail(INFLX_ERR_VERSION);
   }
-  for (int op = 0; op < INFLX_OP_COUNT; ++op) {
-    const std::string names[3] = {std::string("inflx_sweep_tile_") + kOpNames[op], std::string("inflx_sweep_rows_") + kOpNames[op],
-                                  std::string("inflx_sweep_traj_") + kOpNames[op]};
-    hipFunction_t* slots[3] = {&m->tile[op], &m->rows[op], &m->traj[op]};
-    for (int k = 0; k < 3; ++k) {
-      if (hipModuleGetFunction(slots[k], m->module, names[k].c_str()) != hipSuccess) {
-        fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s", artefact_path, names[k].c_str());
-        return bail(INFLX_ERR_SYMBOL);
-      }
-    }
-    const std::string rv = std::string("inflx_sweep_rowvals_") + kOpNames[op];
-    const std::string cv = std::string("inflx_sweep_colvals_") + kOpNames[op];
-    if (hipModuleGetFunction(&m->rowvals[op], m->module, rv.c_str()) != hipSuccess ||
-        hipModuleGetFunction(&m->colvals[op], m->module, cv.c_str()) != hipSuccess) {
-      fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel %s / %s", artefact_path, rv.c_str(), cv.c_str());
-      return bail(INFLX_ERR_SYMBOL);
-    }
-  }
-  if (hipModuleGetFunction(&m->rowstream6, m->module, "inflx_sweep_rowstream6") != hipSuccess ||
-      hipModuleGetFunction(&m->tile_stats, m->module, "inflx_sweep_tile_complete_stats") != hipSuccess ||
-      hipModuleGetFunction(&m->tile_stats_nostore, m->module, "inflx_sweep_tile_complete_stats_nostore") != hipSuccess ||
-      hipModuleGetFunction(&m->rowvals_stats, m->module, "inflx_sweep_rowvals_complete_stats") != hipSuccess ||
-      hipModuleGetFunction(&m->rowstream_planes, m->module, "inflx_sweep_rowstream_planes") != hipSuccess ||
-      hipModuleGetFunction(&m->colstream, m->module, "inflx_sweep_colstream") != hipSuccess ||
-      hipModuleGetFunction(&m->colvals_stats, m->module, "inflx_sweep_colvals_complete_stats") != hipSuccess) {
-    fail(INFLX_ERR_SYMBOL, "artefact %s lacks the row store-stream kernels", artefact_path);
+  char tag[128] = {0};
+  if ((rc = read_global(m, "INFLX_GROUPS", &m->groups, sizeof m->groups, true))) return bail(rc);
+  if ((rc = read_global(m, "MODEL_TAG", tag, sizeof tag - 1, false))) return bail(rc);
+  m->tag = tag;
+  m->groups &= INFLX_GROUP_ALL;
+  if (!(m->groups & INFLX_GROUP_CORE)) {
+    fail(INFLX_ERR_SYMBOL, "artefact %s is not a model's core object (it carries kernel groups 0x%x only): open the core object and attach this one (inflx_attach)", artefact_path, m->groups);
+    m->groups = 0;
     return bail(INFLX_ERR_SYMBOL);
   }
-  if (hipModuleGetFunction(&m->stage_tables, m->module, "inflx_stage_tables") != hipSuccess) {
-    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_stage_tables", artefact_path);
-    return bail(INFLX_ERR_SYMBOL);
-  }
-  if (hipModuleGetFunction(&m->basis_points, m->module, "inflx_basis_points") != hipSuccess) {
-    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_basis_points", artefact_path);
-    return bail(INFLX_ERR_SYMBOL);
-  }
-  if (hipModuleGetFunction(&m->ops_on_values, m->module, "inflx_ops_on_values") != hipSuccess) {
-    fail(INFLX_ERR_SYMBOL, "artefact %s lacks kernel inflx_ops_on_values", artefact_path);
-    return bail(INFLX_ERR_SYMBOL);
+  {
+    const uint32_t present = m->groups;
+    m->groups = 0;
+    if ((rc = resolve_group_kernels(m, m->module, present, artefact_path))) return bail(rc);
+    m->groups = present;
   }
   // (experiment, scripts/tables_policy_probe.py: the side stream at the highest priority the device offers)
   int side_priority = 0;
@@ -1136,9 +1221,22 @@ void inflx_close(inflx_model* m) {
   if (m->stream) (void)hipStreamDestroy(m->stream);
   if (m->side) (void)hipStreamDestroy(m->side);
   if (m->copy_stream) (void)hipStreamDestroy(m->copy_stream);
+  for (hipModule_t extra : m->attached) (void)hipModuleUnload(extra);
   if (m->module) (void)hipModuleUnload(m->module);
   delete m;
 }
+
+int inflx_attach(inflx_model* m, const char* path) {
+  if (!m || !path) return fail(INFLX_ERR_ARG, "model handle / path is NULL");
+  INFLX_SERIALISE(m);
+  FILE* fh = fopen(path, "rb");
+  if (!fh) return fail(INFLX_ERR_IO, "could not open code object %s: %s", path, strerror(errno));
+  fclose(fh);
+  HIP_TRY(hipSetDevice(m->device));
+  return attach_object(m, path);
+}
+
+uint32_t inflx_groups(const inflx_model* m) { return m ? m->groups : 0; }
 
 uint32_t inflx_n_fields(const inflx_model* m) { return m ? m->dim : 0; }
 uint32_t inflx_n_parameters(const inflx_model* m) { return m ? m->n_par : 0; }
@@ -1204,6 +1302,7 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
   const int op = INFLX_OP_COMPLETE;
   int rc = validate(m, op, p, P, n_p);
   if (rc) return rc;
+  if ((rc = need_groups(m, INFLX_GROUP_STATS))) return rc;
   if (!ss || !summary) return fail(INFLX_ERR_ARG, "start_stop / summary pointer is NULL");
   if (row_begin + row_count > N0) return fail(INFLX_ERR_SHAPE, "rows [%zu,%zu) exceed the grid (N0 = %zu)", row_begin, row_begin + row_count, N0);
   if (d_out && d_out_bytes < P * row_count * N1 * kOpBytes[op])
@@ -1369,7 +1468,7 @@ int inflx_sweep_device_timed_ex(inflx_model* m, int op, const double* p, size_t 
 
 int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const double* x, size_t n, double* out) {
   INFLX_SERIALISE(m);
-  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p);
+  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p, /*kernels=*/false);  // (the operation stands for "any": inflx_basis_points is part of the core object)
   if (rc) return rc;
   if (n == 0) return INFLX_OK;
   if (!x || !out) return fail(INFLX_ERR_ARG, "point / output pointer is NULL");
@@ -1401,6 +1500,10 @@ int inflx_ops_on_values(inflx_model* m, const double* values, size_t n, double* 
   if (n == 0) return INFLX_OK;
   if (!values || !out) return fail(INFLX_ERR_ARG, "values / output pointer is NULL");
   HIP_TRY(hipSetDevice(m->device));
+  {
+    const int rcg = need_groups(m, INFLX_GROUP_VALUES);
+    if (rcg) return rcg;
+  }
   const size_t in_bytes = n * 5 * sizeof(double), out_bytes = n * 9 * sizeof(double);
   int rc;
   if ((rc = ensure_chunk(m, 0, out_bytes))) return rc;
@@ -1451,7 +1554,7 @@ int inflx_validate_basis_on_domain(inflx_model* m, const uint32_t* num_points, s
   if (n_axes != m->dim)
     return fail(INFLX_ERR_SHAPE, "expected an array with with the same number of axes as there are field-space coordinates "
                 "(model has %u fields, got %zu)", m->dim, n_axes);
-  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p);
+  int rc = validate(m, INFLX_OP_RAW, p, 1, n_p, /*kernels=*/false);
   if (rc) return rc;
   // src/lib.rs:247-256: every axis in turn is walked from the START corner of the other axis; the walk
   // itself begins at that axis' STOP value (`stop + spacing * idx`) -- reproduced as the reference has it

@@ -3,7 +3,7 @@
 #pragma once
 #include <stdint.h>
 
-#define INFLX_KERNEL_ABI 18u
+#define INFLX_KERNEL_ABI 19u
 
 // which per-point operation a sweep kernel applies (reference src/anguelova.rs `mod ops`)
 enum InflxOp {
@@ -18,6 +18,14 @@ enum InflxOp {
                              //                                 `hesse` returns all four, src/lib.rs:384-420)
   INFLX_OP_COUNT = 7
 };
+
+// Kernel groups of a code object (its INFLX_GROUPS global): a model artefact is the CORE object -- everything complete_analysis
+// needs -- plus, built and loaded on first use, the group of every other operation.  A full artefact carries all of them.
+#define INFLX_GROUP_CORE 1u    // inflx_stage_tables, inflx_sweep_{tile,rows,rowvals,colvals,traj}_complete, the store streams, inflx_basis_points
+#define INFLX_GROUP_STATS 2u   // the fused-summary kernels (*_complete_stats[_nostore])
+#define INFLX_GROUP_VALUES 4u  // inflx_ops_on_values
+#define INFLX_GROUP_OF_OP(op) ((op) == 0 ? INFLX_GROUP_CORE : (8u << ((op)-1)))  // consistency 8, rapidturn 16, epsilon_v 32, raw 64, qdif 128, hesse 256
+#define INFLX_GROUP_ALL 511u
 
 // output memory layout for multi-value operations
 enum InflxLayout {

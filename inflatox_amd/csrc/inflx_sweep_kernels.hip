@@ -109,6 +109,23 @@ INFLX_EXPORT InflxKernelInfo INFLX_KERNEL_INFO = {
     INFLX_KERNEL_ABI, INFLX_NU, INFLX_NR, INFLX_NC, INFLX_OUT_MASK, INFLX_TILE_ROWS, kThreads, INFLX_ROWS_PER_BLOCK,
     kThreads, 0};
 
+// ---- kernel groups: which entry points this code object carries ---------------------------------------------------------------
+// Every kernel that evaluates the model inlines the whole model, and a complete artefact has ~45 of them: building all of it costs
+// a heavy model (D5) 8 s of hipcc, where the reference's one `zig cc` step takes about one (python/inflatox/compiler.py:568-598).
+// A code object therefore carries the groups INFLX_KERNEL_GROUPS names: Compiler.compile() builds the CORE object -- everything
+// complete_analysis needs -- and the groups of the other operations are built when first used and loaded beside it (inflx_attach,
+// or the file `<artefact>.<group>` next to the artefact, which libinflx_hip.so loads on demand).  Default: everything.
+#ifndef INFLX_KERNEL_GROUPS
+#define INFLX_KERNEL_GROUPS 0xffffffffu
+#endif
+#define INFLX_HAS_GROUP(g) ((INFLX_KERNEL_GROUPS & (g)) != 0u)
+INFLX_EXPORT uint32_t INFLX_GROUPS = INFLX_KERNEL_GROUPS & INFLX_GROUP_ALL;
+// which model this is (content hash of the generated header): an attached group must belong to the same one
+#ifndef INFLX_MODEL_TAG
+#define INFLX_MODEL_TAG ""
+#endif
+INFLX_EXPORT char MODEL_TAG[] = INFLX_MODEL_TAG;
+
 template <int OP>
 struct OpWidth {
   static constexpr int K = (OP == INFLX_OP_COMPLETE) ? 6 : (OP == INFLX_OP_RAW ? 5 : (OP == INFLX_OP_HESSE ? 4 : 1));
@@ -797,6 +814,7 @@ __device__ __forceinline__ void sweep_trajectory(const InflxTrajectoryArgs& a) {
 // The kernel is a latency chain, not a throughput problem: U (one lane, dependent instructions), then a row's or a column's values
 // (one lane each).  Rows and columns therefore live in DIFFERENT workgroups -- the chain a lone call waits for in front of its tile
 // kernel is U + max(R, C), not U + R + C as it was while thread i evaluated row i and then column i.
+#if INFLX_HAS_GROUP(INFLX_GROUP_CORE)
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const InflxSweepArgs a) {
   const unsigned tid = threadIdx.x;
   const unsigned p = blockIdx.y;
@@ -841,6 +859,8 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const 
   }
 }
 
+#endif  // INFLX_GROUP_CORE
+
 // ---- entry points (looked up by name with hipModuleGetFunction) --------------------------------
 #define INFLX_DEFINE_KERNELS(NAME, OP)                                                                   \
   extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_##NAME(const InflxSweepArgs a) { \
@@ -859,6 +879,7 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_stage_tables(const 
     sweep_trajectory<OP>(a);                                                                             \
   }
 
+#if INFLX_HAS_GROUP(INFLX_GROUP_CORE)
 // validate_basis_*: v, w1 and their inner products at n explicit points, 7 doubles per point
 // (reference src/lib.rs:149-163 calls the C functions v, w1 and inner_prod per point)
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_basis_points(const InflxTrajectoryArgs a) {
@@ -871,7 +892,16 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_basis_points(const 
 #pragma unroll
   for (int k = 0; k < 7; ++k) a.out[((uint64_t)blockIdx.y * a.n + idx) * 7 + k] = o[k];
 }
+// the store streams (no model code in them)
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream_planes(const InflxSweepArgs a) {
+  sweep_rowstream_planes(a);
+}
+extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colstream(const InflxSweepArgs a) { sweep_colstream(a); }
+INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)
+#endif  // INFLX_GROUP_CORE
 
+#if INFLX_HAS_GROUP(INFLX_GROUP_VALUES)
 // ops::* of src/anguelova.rs:99-171 applied to GIVEN model values -- no model evaluation: a.points holds n records
 // (V, v00, v10, v11, |dV|^2), a.out receives n records of 9 doubles: [0..5] complete_analysis, [6] consistency_only,
 // [7] consistency_rapidturn_only, [8] epsilon_v_only.  a.reserved = 0: complete_analysis exactly as the sweep kernels
@@ -902,8 +932,9 @@ extern "C" __global__ __launch_bounds__(kThreads) void inflx_ops_on_values(const
   dst[7] = inflx_op_consistency_rapidturn_only(mv);
   dst[8] = inflx_op_epsilon_v_only(mv);
 }
+#endif  // INFLX_GROUP_VALUES
 
-extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream6(const InflxSweepArgs a) { sweep_rowstream6(a); }
+#if INFLX_HAS_GROUP(INFLX_GROUP_STATS)
 // complete_analysis with the running summary; the *_nostore variant evaluates and reduces only
 extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sweep_tile_complete_stats(const InflxSweepArgs a) {
   sweep_tile<INFLX_OP_COMPLETE, true, true>(a);
@@ -914,18 +945,26 @@ extern "C" __global__ __launch_bounds__(kThreads, INFLX_MIN_WAVES) void inflx_sw
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowvals_complete_stats(const InflxSweepArgs a) {
   if constexpr ((INFLX_OUT_MASK & 2) == 0) sweep_rowvals<INFLX_OP_COMPLETE, true>(a);
 }
-extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_rowstream_planes(const InflxSweepArgs a) {
-  sweep_rowstream_planes(a);
-}
-extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colstream(const InflxSweepArgs a) { sweep_colstream(a); }
 extern "C" __global__ __launch_bounds__(kThreads) void inflx_sweep_colvals_complete_stats(const InflxSweepArgs a) {
   if constexpr ((INFLX_OUT_MASK & 3) == 2) sweep_colvals<INFLX_OP_COMPLETE, true>(a);
 }
+#endif  // INFLX_GROUP_STATS
 
-INFLX_DEFINE_KERNELS(complete, INFLX_OP_COMPLETE)
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(1))  // INFLX_OP_CONSISTENCY (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(consistency, INFLX_OP_CONSISTENCY)
+#endif
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(2))  // INFLX_OP_RAPIDTURN (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(rapidturn, INFLX_OP_RAPIDTURN)
+#endif
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(3))  // INFLX_OP_EPSILON_V (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(epsilon_v, INFLX_OP_EPSILON_V)
+#endif
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(4))  // INFLX_OP_RAW (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(raw, INFLX_OP_RAW)
+#endif
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(5))  // INFLX_OP_QDIF (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(qdif, INFLX_OP_QDIF)
+#endif
+#if INFLX_HAS_GROUP(INFLX_GROUP_OF_OP(6))  // INFLX_OP_HESSE (an enumerator: the preprocessor needs the number)
 INFLX_DEFINE_KERNELS(hesse, INFLX_OP_HESSE)
+#endif

@@ -225,6 +225,9 @@ class HIPInflatoxPrinter(C99CodePrinter):
         if len(den) == 1:
             recip = self.stager.hoisted_reciprocal(den) if self.stager is not None else None
             if recip is not None:
+                if self.stager.hoist_inline:
+                    # self-checking quotient: no `ok` flag, no second copy of the point stage (inflx_div_by_hoisted_inline)
+                    return f"INFLX_DIVI({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
                 macro = "INFLX_DIVH_PURE" if self.stager.pure_numerator(num, num_s, den[0], den_s[0]) else "INFLX_DIVH"
                 return f"{macro}({sign}{'*'.join(num_s)}, {den_s[0]}, {recip})"
             shared = self.stager.shared_reciprocal(den, den_s[0]) if self.stager is not None else None
@@ -315,7 +318,10 @@ class Stager:
         sys.setrecursionlimit(max(sys.getrecursionlimit(), 50000))
         self.regroup = regroup
         self.staged = staged
-        self.hoist_reciprocals = hoist_reciprocals and staged
+        # "inline": the hoisted quotients check themselves and fall back to the IEEE division on the spot (one point stage,
+        # no `ok` bookkeeping); True: the quick / IEEE pair of point stages with the row redone when a quotient is irregular
+        self.hoist_inline = hoist_reciprocals == "inline" and staged
+        self.hoist_reciprocals = bool(hoist_reciprocals) and staged
         self.x0, self.x1 = x0, x1
         self.printer = HIPInflatoxPrinter(names, self)
         self.lines = {U: [], R: [], C: [], P: []}
@@ -703,7 +709,7 @@ def emit_stage_header(
     The defaults of ``share_point_reciprocals`` (off) and ``quick_sqrt`` (``None``: follows ``hoist_reciprocals``) are
     ``Compiler``'s, so that a direct caller generates the point stage a user gets."""
     if quick_sqrt is None:
-        quick_sqrt = bool(hoist_reciprocals)
+        quick_sqrt = hoist_reciprocals is True or hoist_reciprocals == 1
     x0, x1 = model.coordinates
     exprs = [
         sympy.sympify(model.potential),
@@ -824,16 +830,28 @@ def emit_stage_header(
     if range_flags:
         lines.append("  INFLX_RANGE_CHECK(" + " + ".join(range_flags) + ");")
     point_body = "\n".join(place_imports(imports_for(P, "out"), lines))
+    n_inline = point_body.count("INFLX_DIVI(")
     n_hoisted = point_body.count("INFLX_DIVH(") + point_body.count("INFLX_DIVH_PURE(")
     n_shared = point_body.count("INFLX_DIVS(")
     # square roots of the point stage: the quick variant takes them without operand scaling and zero / infinity selection
     # behind one range test each (inflx_sqrt_checked, csrc/inflx_device_math.h)
-    if quick_sqrt:
+    if quick_sqrt and not n_inline:
         point_body = _SQRT_CALL.sub("INFLX_SQRT(", point_body)
         point_body = _HPOW_CALL.sub(lambda m: f"INFLX_HPOW({m.group(1)}, ", point_body)
     n_sqrt = point_body.count("INFLX_SQRT(") + point_body.count("INFLX_HPOW(")
     out.append("// everything that depends on both axes, and the five model values")
-    if n_hoisted or n_shared or n_sqrt:
+    if n_inline:
+        # ONE point stage.  A quotient whose denominator comes from an earlier stage is formed from that stage's correctly rounded
+        # reciprocal (multiply, FMA, FMA) and accepted by one comparison; a wavefront in which some lane's quotient is not a
+        # regular case divides those lanes the IEEE way on the spot -- the values are the IEEE program's always.
+        out.append(f"// {n_inline} quotients per point by a denominator of an earlier stage, each checking itself (no second copy of the stage)")
+        out.append("#define INFLX_HAS_QUICK_POINT 0")
+        out.append("#define INFLX_DIVI(a, b, y) inflx_div_by_hoisted_inline((a), (b), (y))")
+        out.append(f"INFLX_FN void inflx_stage_point({point_args}) {{")
+        out.append(point_body)
+        out.append("}")
+        out.append("#undef INFLX_DIVI\n")
+    elif n_hoisted or n_shared or n_sqrt:
         # The same statements twice.  `quick` forms the quotients whose denominator comes from an earlier
         # stage with inflx_div_by_hoisted (three full-rate instructions instead of an IEEE division) and
         # reports in `ok` whether every one of them was a regular case; `ieee` divides.  A point that is not
@@ -882,6 +900,7 @@ def emit_stage_header(
     sweep_lines = "\n".join(ln for ln in point_body.splitlines() if not ln.lstrip().startswith(("mv.b0", "mv.b1")))
     info = dict(
         nu=nu, nr=nr, nc=nc, out_mask=st.out_mask, out_masks=list(st.out_masks), statements={str(k): v for k, v in counts.items()},
+        inline_quotients=sweep_lines.count("INFLX_DIVI("),
         hoisted_quotients=sweep_lines.count("INFLX_DIVH(") + sweep_lines.count("INFLX_DIVH_PURE("),
         pure_quotients=sweep_lines.count("INFLX_DIVH_PURE("),
         shared_quotients=sweep_lines.count("INFLX_DIVS("),
@@ -939,8 +958,11 @@ def _emit_basis_point(model, x0, x1, names, param_slots, tail, cse_vector):
         names[sym] = param_slots[plain(sym)]
     functions = [cse_vector(vec) if cse_vector is not None else ([], vec) for vec in vectors]
     functions.append(cse_vector(metric) if cse_vector is not None else ([], metric))
-    st = Stager(functions, x0, x1, names, staged=False)
-    lines = list(st.lines[P])
+    # staged like the sweep values -- identical nodes once, pow chains -- with every stage inline, evaluated per point (exact in the
+    # sense of the module docstring): printed as the reference's three separate C functions this helper was 200 kB of text for D5 and
+    # two thirds of the model's whole hipcc time
+    st = Stager(functions, x0, x1, names, staged=True)
+    lines = [ln for m in (U, R, C, P) for ln in st.lines[m]]
     texts = list(st.outputs)
     comps = ["bv", "bw"]
     for k in range(dim):

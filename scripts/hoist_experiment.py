@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Experiment (GPU box): tile-kernel time of the hoisted-reciprocal division against the default.
-usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, nohoist, regroup, share, nosqrt, tanN (tan_shortcut=N), trust (-DINFLX_DIVH_TRUST: accept every quotient),
+usage: hoist_experiment.py MODEL[:flag,flag...] ...   flags: hoist, nohoist, inline (self-checking hoisted quotients, one point stage), regroup, share, nosqrt, tanN (tan_shortcut=N), trust (-DINFLX_DIVH_TRUST: accept every quotient),
 wN (N waves/SIMD: -DINFLX_MIN_WAVES=N), inner (grid away from the first row/column), DNAME=value (any -D switch of the kernel sources, e.g.
 DINFLX_HORNER_MODE=0, DINFLX_EXPERIMENT_IEEE_EPILOGUE=1, DINFLX_TAN_SHORTCUT_MAX=16)"""
 import os
@@ -45,7 +45,7 @@ for case in cases * rounds:
     if "inner" in fl:  # keep away from the first row and the first column
         x0a, x0b, x1a, x1b = ext
         ext = (x0a + 0.1 * (x0b - x0a), x0b, x1a + 0.1 * (x1b - x1a), x1b)
-    hoist = True if "hoist" in fl else (False if "nohoist" in fl else None)  # default: the compiler's automatic choice
+    hoist = True if "hoist" in fl else (False if "nohoist" in fl else ("inline" if "inline" in fl else None))  # default: the compiler's automatic choice
     if "regroup" in fl:
         kw["regroup"] = True
     if "share" in fl:

@@ -59,7 +59,7 @@ def report(spec_text: str):
         elif k.startswith("D"):
             flags.append(f"-{k}={v}")
         else:
-            kw[k] = bool(int(v))
+            kw[k] = bool(int(v)) if v.lstrip('-').isdigit() else v  # (hoist_reciprocals=inline)
     art = Compiler(workloads.model_for(name), silent=True, compiler_flags=flags, **kw).compile()
     path = art.shared_object_path
     notes = subprocess.run([READELF, "--notes", path], capture_output=True, text=True).stdout
@@ -79,7 +79,7 @@ def report(spec_text: str):
     hdr = open(art.header_path).read()
     print(
         f"{spec_text:40s} vgpr={info.get('vgpr_count')} spill={info.get('vgpr_spill_count')} scratch={info.get('private_segment_fixed_size')}B lds={info.get('group_segment_fixed_size')}B"
-        f" | hoisted quotients: {hdr.count('INFLX_DIVH(') // 2 if 'INFLX_DIVH(' in hdr else 0} | NU/NR/NC={art.stage_info['nu']}/{art.stage_info['nr']}/{art.stage_info['nc']}",
+        f" | hoisted quotients: {hdr.count('INFLX_DIVH(') // 2 if 'INFLX_DIVH(' in hdr else 0}, inline: {art.stage_info.get('inline_quotients', 0)} | NU/NR/NC={art.stage_info['nu']}/{art.stage_info['nr']}/{art.stage_info['nc']}",
         flush=True,
     )
     for loop in loops_of(asm[start:end]):

@@ -64,13 +64,50 @@ def test_code_object_exports_the_model_abi():
 
         pytest.skip("llvm-readelf not available")
     _, art = workloads.artifact_for("hyperbolic")
-    table = subprocess.run([readelf, "-s", "--dyn-syms", art.shared_object_path], capture_output=True, text=True, check=True).stdout
-    exported = {ln.split()[-1] for ln in table.splitlines() if " GLOBAL " in ln}
-    for sym in ("VERSION", "DIM", "N_PARAMETERS", "MODEL_NAME", "USE_GSL", "INFLX_KERNEL_INFO"):
-        assert sym in exported, sym
-    for op in ("complete", "consistency", "rapidturn", "epsilon_v", "raw"):
+
+    def exports(path):
+        table = subprocess.run([readelf, "-s", "--dyn-syms", path], capture_output=True, text=True, check=True).stdout
+        return {ln.split()[-1].removesuffix(".kd") for ln in table.splitlines() if " GLOBAL " in ln}  # (kernels also export a descriptor NAME.kd)
+
+    data = ("VERSION", "DIM", "N_PARAMETERS", "MODEL_NAME", "USE_GSL", "INFLX_KERNEL_INFO", "INFLX_GROUPS", "MODEL_TAG")
+    # what Compiler.compile() builds: the CORE object -- the reference's data symbols and every kernel complete_analysis needs
+    core = exports(art.shared_object_path)
+    for sym in data:
+        assert sym in core, sym
+    for sym in ("inflx_stage_tables", "inflx_basis_points", "inflx_sweep_rowstream6", "inflx_sweep_rowstream_planes", "inflx_sweep_colstream"):
+        assert sym in core, sym
+    for kind in ("tile", "rows", "rowvals", "colvals", "traj"):
+        assert f"inflx_sweep_{kind}_complete" in core
+    assert not any(name.startswith("inflx_sweep_tile_") and name != "inflx_sweep_tile_complete" for name in core), sorted(core)
+    # every other operation: a group object of its own, built on first use, with the same data symbols (inflx_attach compares them)
+    for group, kernels in (("consistency", ["inflx_sweep_tile_consistency", "inflx_sweep_traj_consistency"]), ("raw", ["inflx_sweep_tile_raw", "inflx_sweep_rows_raw"]),
+                           ("stats", ["inflx_sweep_tile_complete_stats", "inflx_sweep_tile_complete_stats_nostore", "inflx_sweep_rowvals_complete_stats"]), ("values", ["inflx_ops_on_values"])):
+        path = art.ensure_group(group)
+        assert path == art.shared_object_path + "." + group and os.path.getsize(path) > 0
+        got = exports(path)
+        for sym in data + tuple(kernels):
+            assert sym in got, (group, sym)
+        assert "inflx_sweep_tile_complete" not in got and "inflx_stage_tables" not in got
+    assert art.ensure_group("core") is None
+    # a complete artefact in one file, for a C client that wants one
+    from inflatox_amd.compiler import Compiler
+    from workloads import example_models
+
+    full = Compiler(workloads.model_for("hyperbolic"), silent=True, kernel_groups="all", **example_models.get("hyperbolic").compiler_kwargs).compile()
+    everything = exports(full.shared_object_path)
+    for op in ("complete", "consistency", "rapidturn", "epsilon_v", "raw", "qdif", "hesse"):
         for kind in ("tile", "rows", "traj"):
-            assert f"inflx_sweep_{kind}_{op}" in exported
+            assert f"inflx_sweep_{kind}_{op}" in everything
+    assert "inflx_ops_on_values" in everything and "inflx_sweep_tile_complete_stats" in everything
+    assert full.ensure_group("raw") is None and full.ensure_all_groups() == []
+    # the sidecars go with the artefact
+    paths = [art.shared_object_path] + [art.shared_object_path + "." + g for g in ("consistency", "raw", "stats", "values")]
+    assert all(os.path.exists(q) for q in paths)
+    del art
+    import gc
+
+    gc.collect()
+    assert not any(os.path.exists(q) for q in paths)
 
 
 def test_host_helpers_under_address_and_ub_sanitizers(tmp_path):

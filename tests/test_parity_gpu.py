@@ -1086,6 +1086,7 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     import subprocess
 
     from inflatox_amd import _native
+    from inflatox_amd.compiler import Compiler
 
     import workloads
 
@@ -1099,9 +1100,23 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     spec, art, lib = devlib("doc", gpu_lib)
     n0, n1 = 64, 48
     out = tmp_path / "out.bin"
-    cmd = [str(exe), art.shared_object_path, str(n0), str(n1), *[repr(float(v)) for v in spec.extent], str(out), *[repr(float(v)) for v in spec.args]]
+    tail = [str(n0), str(n1), *[repr(float(v)) for v in spec.extent], str(out), *[repr(float(v)) for v in spec.args]]
+    # the client calls complete_analysis and consistency_only.  (1) A fresh core object alone: complete_analysis runs, consistency_only is
+    # refused with INFLX_ERR_SYMBOL and a message that names the missing group and where it is looked for
+    _, core_only = workloads.artifact_for("doc")
+    proc = subprocess.run([str(exe), core_only.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 7 and f"({_native.ERR_SYMBOL})" in proc.stderr and '"consistency"' in proc.stderr and core_only.shared_object_path + ".consistency" in proc.stderr, (proc.returncode, proc.stderr)
+    # (2) the group next to the artefact, as `<artefact>.consistency`: the library loads it on demand
+    assert core_only.ensure_group("consistency") == core_only.shared_object_path + ".consistency"
+    proc = subprocess.run([str(exe), core_only.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
+    assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
+    first = np.fromfile(out, dtype=np.float64)
+    # (3) a complete artefact in one file
+    full = Compiler(workloads.model_for("doc"), silent=True, kernel_groups="all", **spec.compiler_kwargs).compile()
+    cmd = [str(exe), full.shared_object_path, *tail]
     proc = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
+    assert np.array_equal(first, np.fromfile(out, dtype=np.float64), equal_nan=True)
     data = np.fromfile(out, dtype=np.float64)
     six, one = data[: n0 * n1 * 6].reshape(n0, n1, 6), data[n0 * n1 * 6 :].reshape(n0, n1)
     ss = np.array(spec.extent).reshape(2, 2)
@@ -1112,6 +1127,62 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     bogus.write_bytes(b"not a code object")
     proc = subprocess.run([str(exe), str(bogus), "4", "4", "0", "1", "0", "1", str(out), "1.0"], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 3 and "inflx_open failed (1)" in proc.stderr
+
+
+def test_kernel_groups_are_built_and_attached_on_first_use(gpu_lib):
+    """Compiler.compile() builds the core object (one hipcc step, like the reference's one `zig cc` step,
+    python/inflatox/compiler.py:568-598); an operation other than complete_analysis builds and attaches its kernel group when it is
+    first used -- and only then; a group object of another model or other options is refused; results do not depend on how the
+    kernels arrived (a complete artefact gives the same bits)."""
+    from inflatox_amd.compiler import KERNEL_GROUPS, Compiler
+
+    import workloads
+
+    spec, art = workloads.artifact_for("doc")
+    assert art.kernel_groups == KERNEL_GROUPS["core"]
+    lib = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    assert lib.groups == KERNEL_GROUPS["core"]
+    n0, n1 = 70, 300
+    full_art = Compiler(workloads.model_for("doc"), silent=True, kernel_groups="all", **spec.compiler_kwargs).compile()
+    full = gpu_lib.InflatoxDevLib(full_art.shared_object_path)
+    assert full.groups == 511
+    six = lib.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1)
+    assert lib.groups == KERNEL_GROUPS["core"]  # complete_analysis needs nothing else
+    assert np.array_equal(six, full.sweep_host(gpu_lib.OP_COMPLETE, spec.args, spec.extent, n0, n1), equal_nan=True)
+    seen = KERNEL_GROUPS["core"]
+    for op, group in ((gpu_lib.OP_EPSILON_V, "epsilon_v"), (gpu_lib.OP_RAW, "raw"), (gpu_lib.OP_HESSE, "hesse"), (gpu_lib.OP_CONSISTENCY, "consistency"), (gpu_lib.OP_RAPIDTURN, "rapidturn")):
+        got = lib.sweep_host(op, spec.args, spec.extent, n0, n1)
+        seen |= KERNEL_GROUPS[group]
+        assert lib.groups == seen, (group, lib.groups)
+        assert np.array_equal(got, full.sweep_host(op, spec.args, spec.extent, n0, n1), equal_nan=True), group
+        pts = np.column_stack([np.linspace(spec.extent[0], spec.extent[1], 9, endpoint=False), np.linspace(spec.extent[2], spec.extent[3], 9, endpoint=False)])
+        assert np.array_equal(lib.sweep_on_trajectory(op, spec.args, pts), full.sweep_on_trajectory(op, spec.args, pts), equal_nan=True)
+    stats = lib.sweep_stats(spec.args, spec.extent, n0, n1)
+    assert lib.groups == seen | KERNEL_GROUPS["stats"]
+    assert np.array_equal(stats["max"], np.nanmax(six.reshape(-1, 6), axis=0))
+    flags = np.zeros((n0, n1), dtype=bool)
+    lib.flag_quantum_dif(spec.args, flags, np.array(spec.extent).reshape(2, 2))
+    lib.ops_on_values(np.ones((4, 5)))
+    assert lib.groups == 511
+    # a second handle on the same artefact finds the groups the first one built (the files next to the artefact)
+    again = gpu_lib.InflatoxDevLib(art.shared_object_path)
+    assert again.groups == KERNEL_GROUPS["core"]
+    assert np.array_equal(again.sweep_host(gpu_lib.OP_RAW, spec.args, spec.extent, n0, n1), full.sweep_host(gpu_lib.OP_RAW, spec.args, spec.extent, n0, n1), equal_nan=True)
+    # an object of another model, or of this model under other options, is refused -- and the handle keeps working
+    _, other = workloads.artifact_for("egno")
+    _, tuned = workloads.artifact_for("doc", tan_shortcut=16)
+    lonely_spec, lonely = workloads.artifact_for("doc")
+    h = gpu_lib.InflatoxDevLib(lonely.shared_object_path)
+    for wrong in (other.ensure_group("raw"), tuned.ensure_group("raw")):
+        with pytest.raises(SystemError, match="does not belong to artefact"):
+            gpu_lib._check(gpu_lib.load_library().inflx_attach(h._h, os.fsencode(wrong)))
+    with pytest.raises(IOError):
+        gpu_lib._check(gpu_lib.load_library().inflx_attach(h._h, b"/nonexistent/group.hsaco"))
+    assert h.groups == KERNEL_GROUPS["core"]
+    assert np.array_equal(h.sweep_host(gpu_lib.OP_RAW, lonely_spec.args, lonely_spec.extent, n0, n1), full.sweep_host(gpu_lib.OP_RAW, spec.args, spec.extent, n0, n1), equal_nan=True)
+    # a group object is not an artefact
+    with pytest.raises(SystemError, match="not a model's core object"):
+        gpu_lib.InflatoxDevLib(lonely.shared_object_path + ".raw")
 
 
 def test_artefacts_of_another_abi_version_or_dimension_are_refused(gpu_lib, tmp_path):
