@@ -133,6 +133,18 @@ def cpu_baseline(model_name: str, args, extent, budget_s: float = 12.0):
     }
 
 
+HBM_HEADROOM_BYTES = 16 << 30  # left free beside the resident result block: stage / row tables, RCCL buffers, the allocator's slack
+
+
+def choose_rows_per_gpu(requested: int, free_bytes: int, row_bytes: int, headroom: int = HBM_HEADROOM_BYTES) -> int:
+    """Parameter rows of the resident result block of one rank, decided UP FRONT from the HBM that is free on its device
+    (torch.cuda.mem_get_info) instead of asking for the full block and halving on failure: the requested number (64 = BASELINE
+    configs[4] on 8 GPUs, 206 GB) if it fits beside `headroom`, else as many rows as do -- at least one.  Every rank computes its
+    own figure and the ranks agree on the smallest (weak scaling: the same work per GPU) before anything is allocated."""
+    fit = max(0, int(free_bytes) - int(headroom)) // max(1, int(row_bytes))
+    return int(max(1, min(int(requested), fit)))
+
+
 def self_launch(opt) -> int:
     """`python bench.py --gpus N` with N > 1 and no launcher around it: start torch.distributed.run as a child
     (this process has not imported torch, let alone touched a GPU) and hand its exit code on."""
@@ -529,34 +541,46 @@ def main():
     rows_requested = rows_per_gpu
     if distributed:
         assert dist.get_world_size() == opt.gpus == world, (dist.get_world_size(), opt.gpus, world)
-    # The result block stays resident: rows_per_gpu x 3.2 GB (206 GB at the default 64).  If a rank cannot allocate that
-    # (a GPU with less free HBM than a fresh MI355X offers, another tenant on the device), the block is halved until it fits --
-    # on EVERY rank, to the smallest size any rank got (weak scaling: the same work per GPU) -- in this process, and the line
-    # says which size ran (`config.parameter_rows_per_gpu`, `config.rows_per_gpu_requested`).  INFLX_BENCH_MAX_BLOCK_GB caps
-    # the block artificially (the two-rank rehearsal tests force the degrade path with it).
+    # The result block stays resident: rows_per_gpu x 3.2 GB (206 GB at the default 64 = 72 % of a fresh MI355X's HBM).  How many rows
+    # fit is decided up front from the HBM that is free on the rank's device (choose_rows_per_gpu) -- another tenant on the GPU, a
+    # smaller part -- and agreed on by all ranks (the smallest figure: weak scaling, the same work per GPU) BEFORE anything is
+    # allocated; the line says what ran (`config.parameter_rows_per_gpu`, `config.rows_per_gpu_requested`, `config.hbm_free_gb_at_start`).
+    # INFLX_BENCH_MAX_BLOCK_GB caps the free figure artificially (the rehearsal tests shrink the block with it).  Should the
+    # allocation fail all the same (fragmentation), the block is halved -- on every rank -- until it fits.
     cap_gb = float(os.environ.get("INFLX_BENCH_MAX_BLOCK_GB", "0") or 0)
-    out = None
-    while True:
-        want_bytes = rows_per_gpu * N0 * N1 * 6 * 8
-        try:
-            if cap_gb and want_bytes > cap_gb * 1e9:
-                raise torch.OutOfMemoryError(f"INFLX_BENCH_MAX_BLOCK_GB={cap_gb}: refusing {want_bytes / 1e9:.1f} GB")
-            out = torch.empty((rows_per_gpu, N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
-            break
-        except (torch.OutOfMemoryError, RuntimeError) as exc:
-            if rows_per_gpu == 1:
-                raise
-            print(f"[bench rank {rank}] {rows_per_gpu} rows per GPU do not fit ({str(exc).splitlines()[0][:120]}): trying {rows_per_gpu // 2}", file=sys.stderr, flush=True)
-            rows_per_gpu //= 2
-            torch.cuda.empty_cache()
+    row_bytes = N0 * N1 * 6 * 8
+    free_bytes = int(torch.cuda.mem_get_info(local_rank)[0])
+    if cap_gb:
+        free_bytes = min(free_bytes, int(cap_gb * 1e9) + HBM_HEADROOM_BYTES)
+    rows_per_gpu = choose_rows_per_gpu(rows_requested, free_bytes, row_bytes)
     if distributed:
         agreed = torch.tensor([rows_per_gpu], dtype=torch.int64, device=comm_device)
         dist.all_reduce(agreed, op=dist.ReduceOp.MIN)
-        if int(agreed.item()) != rows_per_gpu:
-            rows_per_gpu = int(agreed.item())
-            del out
-            torch.cuda.empty_cache()
+        rows_per_gpu = int(agreed.item())
+    if rows_per_gpu != rows_requested:
+        print(f"[bench rank {rank}] {rows_requested} rows per GPU requested, {free_bytes / 1e9:.0f} GB free on device {local_rank}: sweeping {rows_per_gpu} rows per GPU", file=sys.stderr, flush=True)
+    out = None
+    while True:
+        try:
             out = torch.empty((rows_per_gpu, N0, N1, 6), dtype=torch.float64, device=f"cuda:{local_rank}")
+            ok = 1
+        except (torch.OutOfMemoryError, RuntimeError) as exc:
+            if rows_per_gpu == 1 and not distributed:
+                raise
+            print(f"[bench rank {rank}] {rows_per_gpu} rows per GPU could not be allocated ({str(exc).splitlines()[0][:120]})", file=sys.stderr, flush=True)
+            ok = 0
+            torch.cuda.empty_cache()
+        if distributed:  # every rank must hold the same block: halve everywhere if any rank failed
+            flag = torch.tensor([ok], dtype=torch.int64, device=comm_device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = int(flag.item())
+        if ok:
+            break
+        if rows_per_gpu == 1:
+            raise SystemExit("not even one parameter row fits on every rank's device")
+        out = None
+        torch.cuda.empty_cache()
+        rows_per_gpu //= 2
     total_rows = rows_per_gpu * world
     all_rows = np.tile(np.array(spec.args, dtype=np.float64), (total_rows, 1))
     if total_rows > 1:
@@ -691,7 +715,8 @@ def main():
                 ),
                 "untimed_sweeps_before_warmup": settle_steps * rows_per_gpu,  # clock settling, see the comment at the warm-up loop
                 "parameter_rows_per_gpu": rows_per_gpu,
-                "rows_per_gpu_requested": rows_requested,  # larger than parameter_rows_per_gpu: the block was halved until every rank could allocate it
+                "rows_per_gpu_requested": rows_requested,  # larger than parameter_rows_per_gpu: the block was sized to the HBM free on the ranks' devices
+                "hbm_free_gb_at_start": round(free_bytes / 1e9, 1),  # rank 0's device, before the result block was allocated
                 "parameter_rows_total": total_rows,
                 "baseline_config": "configs[1]" if total_rows == 1 else ("configs[4]" if (total_rows, N0) == (512, 8192) else f"configs[4] axis, first {total_rows} of 512 rows"),
                 "parallelism": (f"parameter-axis x{world} (plan_shard, no data-path collective)" if world > 1 else "single GPU") + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearse else ""),

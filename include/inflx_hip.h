@@ -358,6 +358,10 @@ int inflx_sweep_allgather_multi(inflx_multi* multi, int op, const double* p, siz
  *                             device; INFLX_ERR_SHAPE / INFLX_ERR_ARG otherwise.  RCCL is bound at run time (the copy already
  *                             mapped into the process if there is one, e.g. PyTorch's, else librccl.so.1): libinflx_hip.so
  *                             does not link it, and a caller that never asks for it never loads it.
+ *                             EXPERIMENTAL until a run on two or more GPUs has passed: no node with more than one GPU has been
+ *                             available to this build, so the collective has executed with one rank only; the (send, recv, count) of
+ *                             every rank are checked against inflx_shard_plan on the host (tests/host_units.cpp).  On an error the
+ *                             call waits for every device's streams before it returns.
  */
 typedef enum inflx_gather {
   INFLX_GATHER_PEER_PUSH = 0,

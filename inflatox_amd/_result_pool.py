@@ -38,6 +38,47 @@ import numpy as np
 
 
 
+_V1_UNLIMITED = 0x7FFFFFFFFFFFF000  # what cgroup v1 reports for "no limit" (PAGE_COUNTER_MAX rounded to pages)
+
+
+def _levels(path: str):
+    """A cgroup path and every ancestor of it: "/a/b/c" -> "/a/b/c", "/a/b", "/a", ""."""
+    path = path.rstrip("/")
+    while True:
+        yield path
+        if not path:
+            return
+        path = path.rsplit("/", 1)[0]
+
+
+def cgroup_memory_limits(proc_cgroup: str = "/proc/self/cgroup", v2_mount: str = "/sys/fs/cgroup", v1_mount: str = "/sys/fs/cgroup/memory") -> list[int]:
+    """Every memory limit in force on the way from this process's cgroup up to the hierarchy root (bytes; "max" and the v1
+    "unlimited" sentinel are no limits).  Inside a container the process's path usually does not exist below the mount: the levels
+    that are missing are skipped and the root file still counts."""
+    paths = {"v2": [""], "v1": [""]}
+    try:
+        with open(proc_cgroup) as fh:
+            for line in fh:
+                _, controllers, path = line.rstrip("\n").split(":", 2)
+                if controllers == "":
+                    paths["v2"] = list(_levels(path))
+                elif "memory" in controllers.split(","):
+                    paths["v1"] = list(_levels(path))
+    except (OSError, ValueError):
+        pass
+    limits = []
+    for files in ([f"{v2_mount}{lvl}/memory.max" for lvl in paths["v2"]], [f"{v1_mount}{lvl}/memory.limit_in_bytes" for lvl in paths["v1"]]):
+        for name in files:
+            try:
+                with open(name) as fh:
+                    value = int(fh.read().strip())
+            except (OSError, ValueError):  # no such level here, or "max"
+                continue
+            if 0 < value < _V1_UNLIMITED:
+                limits.append(value)
+    return limits
+
+
 def _default_limit() -> int:
     env = os.environ.get("INFLX_RESULT_POOL_MB")
     if env is not None:
@@ -50,24 +91,9 @@ def _default_limit() -> int:
     except (ValueError, OSError):
         memory = 8 << 30
     # a container's (or a batch job's) share of it: cgroup v2 `memory.max`, cgroup v1 `memory.limit_in_bytes` (what SLURM's
-    # task/cgroup plugin and older container runtimes set) -- the process's own cgroup first, then the hierarchy root
-    candidates = ["/sys/fs/cgroup/memory.max", "/sys/fs/cgroup/memory/memory.limit_in_bytes"]
-    try:
-        with open("/proc/self/cgroup") as fh:
-            for line in fh:
-                _, controllers, path = line.rstrip("\n").split(":", 2)
-                if controllers == "":  # v2
-                    candidates.insert(0, f"/sys/fs/cgroup{path}/memory.max")
-                elif "memory" in controllers.split(","):  # v1
-                    candidates.insert(0, f"/sys/fs/cgroup/memory{path}/memory.limit_in_bytes")
-    except (OSError, ValueError):
-        pass
-    for path in candidates:
-        try:
-            with open(path) as fh:
-                memory = min(memory, int(fh.read().strip()))
-        except (OSError, ValueError):  # no such file, or no limit ("max")
-            pass
+    # task/cgroup plugin and older container runtimes set).  A limit may sit on ANY level between the process's own cgroup and the
+    # root -- a systemd slice, SLURM's job and step levels --: walk upwards and take the smallest
+    memory = min([memory] + cgroup_memory_limits())
     return max(1 << 30, min(memory // 8, 16 << 30))
 
 

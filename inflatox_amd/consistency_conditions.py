@@ -9,6 +9,8 @@ separate methods (``complete_analysis_batch``), so reference call sites run unch
 
 from __future__ import annotations
 
+import threading
+
 import numpy as np
 
 from . import _native
@@ -50,26 +52,38 @@ class InflationCondition:
             device = self.multi.devices[0]
         self.dylib: InflatoxDevLib = open_inflx_dylib(compiled_artifact.shared_object_path, validate_basis, device=device)
         self._tune_pending = bool(tuned)
+        self._tune_lock = threading.Lock()  # two first sweeps that arrive together measure and swap handles once
         self.tuned_on = None  # (args, extent) the profile-guided build was measured on
 
     def retune(self, args, extent) -> None:
         """Extension: (re)build the profile-guided code object for the parameter values ``args`` and the field range
-        ``extent = (x0_start, x0_stop, x1_start, x1_stop)`` and run every later call of this object on it."""
+        ``extent = (x0_start, x0_stop, x1_start, x1_stop)`` and run every later call of this object on it.  The handles of the build
+        in use so far are closed (their device buffers and streams are released at once, not at some later garbage collection)."""
         sample_args = np.asarray(args, dtype=np.float64)
         sample_args = sample_args.reshape(-1, sample_args.shape[-1])[0]  # a batch is measured on its first parameter row
         extent = tuple(float(v) for v in np.asarray(extent, dtype=np.float64).reshape(-1))
         art = self.artifact.profile_guided(sample_args, extent)
         device = self.dylib.device
-        if self._devices is not None:
-            self.multi = InflatoxMultiLib(art.shared_object_path, self._devices)
-        self.dylib = open_inflx_dylib(art.shared_object_path, False, device=device)  # the basis was validated on the default build
-        self.artifact = art
+        new_multi = InflatoxMultiLib(art.shared_object_path, self._devices) if self._devices is not None else None
+        new_dylib = open_inflx_dylib(art.shared_object_path, False, device=device)  # the basis was validated on the default build
+        old_dylib, old_multi = self.dylib, self.multi
+        self.dylib, self.multi, self.artifact = new_dylib, new_multi, art
         self._tune_pending = False
         self.tuned_on = (sample_args.copy(), extent)
+        old_dylib.close()
+        if old_multi is not None:
+            old_multi.close()
 
     def _before_sweep(self, args, start_stop) -> None:
+        """With ``tuned=True``: the first call that knows its parameter values AND a field range -- every grid sweep -- measures and
+        switches builds, once (concurrent first calls wait for the one that does).  Calls made before that -- and the calls that have
+        no range to measure on: ``calc_V`` / ``calc_H``, the ``*_ot`` variants, the basis validation -- run on
+        the default build, i.e. in the reference's arithmetic; after the first grid sweep they run on the profile-guided build like
+        everything else (same parity criterion; ``tuned_on`` says whether and on what the object has switched)."""
         if self._tune_pending:
-            self.retune(args, start_stop)
+            with self._tune_lock:
+                if self._tune_pending:
+                    self.retune(args, start_stop)
 
     # -- scalar helpers (reference :52-65,103-117); evaluated on the device through the raw op ----
     def _raw_at(self, x, args) -> np.ndarray:
@@ -301,6 +315,7 @@ class GeneralisedAL(InflationCondition):
     def flag_quantum_dif(self, args, x0_start, x0_stop, x1_start, x1_stop, N_x0=10_000, N_x1=10_000, progress=True, accuracy=1e-3) -> np.ndarray:
         """Boolean (N_x0, N_x1) array: True where both components of the normalised potential gradient
         are <= ``accuracy`` (reference consistency_conditions.py:477-523, src/anguelova.rs:166-170)."""
+        self._before_sweep(args, (x0_start, x0_stop, x1_start, x1_stop))
         x = result_array((N_x0, N_x1), dtype=bool)
         self.dylib.flag_quantum_dif(args, x, _start_stop(x0_start, x0_stop, x1_start, x1_stop), progress, accuracy)
         return x

@@ -2168,7 +2168,10 @@ struct RcclApi {
 };
 constexpr int kNcclFloat64 = 8;  // ncclDataType_t::ncclFloat64 (rccl.h)
 
-const RcclApi* rccl_api() {
+// (`why`: filled when the library or one of its symbols could not be bound -- the text is captured where dlopen / dlsym failed, once;
+// dlerror() itself is per-thread state that the next dl* call of anybody overwrites)
+const RcclApi* rccl_api(std::string* why = nullptr) {
+  static std::string failure;
   static const RcclApi api = [] {
     RcclApi a;
     void* h = nullptr;
@@ -2176,18 +2179,49 @@ const RcclApi* rccl_api() {
     for (const char* nm : names)
       if ((h = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) { a.origin = std::string(nm) + " (already mapped)"; break; }
     if (!h)
-      for (const char* nm : names)
+      for (const char* nm : names) {
         if ((h = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) { a.origin = nm; break; }
+        const char* e = dlerror();
+        failure += std::string(failure.empty() ? "" : "; ") + nm + ": " + (e ? e : "not found");
+      }
     if (!h) return a;
-    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(dlsym(h, "ncclCommInitAll"));
-    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
-    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(dlsym(h, "ncclAllGather"));
-    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(dlsym(h, "ncclGroupStart"));
-    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(dlsym(h, "ncclGroupEnd"));
-    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
+    failure.clear();
+    auto bind = [&](const char* sym) -> void* {
+      void* fn = dlsym(h, sym);
+      if (!fn) failure += std::string(failure.empty() ? "" : ", ") + sym;
+      return fn;
+    };
+    a.CommInitAll = reinterpret_cast<decltype(a.CommInitAll)>(bind("ncclCommInitAll"));
+    a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(bind("ncclCommDestroy"));
+    a.AllGather = reinterpret_cast<decltype(a.AllGather)>(bind("ncclAllGather"));
+    a.GroupStart = reinterpret_cast<decltype(a.GroupStart)>(bind("ncclGroupStart"));
+    a.GroupEnd = reinterpret_cast<decltype(a.GroupEnd)>(bind("ncclGroupEnd"));
+    a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(bind("ncclGetErrorString"));
+    if (!failure.empty()) failure = a.origin + " lacks " + failure;
     return a;
   }();
-  return (api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString) ? &api : nullptr;
+  const bool ok = api.CommInitAll && api.CommDestroy && api.AllGather && api.GroupStart && api.GroupEnd && api.GetErrorString;
+  if (!ok && why) *why = failure.empty() ? "library or symbols missing" : failure;
+  return ok ? &api : nullptr;
+}
+
+// What the in-place RCCL all-gather of a sharded sweep hands ncclAllGather, per (image q, rank k): byte offsets into rank k's full-size
+// buffer of its own block (send) and of the image (recv), and the element count of one block.  Split along the parameter axis the whole
+// (P, N0, N1, K) array is ONE image; split along grid rows every parameter row is one (its blocks are contiguous within the row's
+// (N0, N1, K) image).  rccl.h's in-place rule: sendbuff == recvbuff + rank * sendcount.  (A function of its own so that the offsets can
+// be checked against shard_plan without a second GPU: tests/host_units.cpp.)
+struct GatherCall {
+  size_t image, rank, send_off, recv_off, count;
+};
+std::vector<GatherCall> rccl_gather_calls(size_t P, size_t N0, size_t row_bytes, size_t world) {
+  std::vector<GatherCall> calls;
+  const ShardPlan s0 = shard_plan(P, N0, world, 0);
+  const size_t images = s0.axis == 0 ? 1 : P;
+  const size_t block_bytes = s0.axis == 0 ? s0.p_count * N0 * row_bytes : s0.row_count * row_bytes;
+  const size_t image_bytes = s0.axis == 0 ? P * N0 * row_bytes : N0 * row_bytes;
+  for (size_t q = 0; q < images; ++q)
+    for (size_t k = 0; k < world; ++k) calls.push_back({q, k, q * image_bytes + k * block_bytes, q * image_bytes, block_bytes / sizeof(double)});
+  return calls;
 }
 
 #define RCCL_TRY(api, expr)                                                                                       \
@@ -2589,14 +2623,20 @@ int inflx_sweep_allgather_multi_ex(inflx_multi* mm, int op, const double* p, siz
     for (size_t k = 0; k < world; ++k)
       for (size_t j = k + 1; j < world; ++j)
         if (d_full[k] == d_full[j]) return fail(INFLX_ERR_ARG, "the RCCL all-gather needs a buffer per device (buffers %zu and %zu are the same)", k, j);
-    if (!(api = rccl_api())) {
-      const char* why = dlerror();  // (one call: dlerror() clears the message it returns)
-      return fail(INFLX_ERR_DEVICE, "RCCL (librccl.so) could not be loaded: %s", why ? why : "library or symbols missing");
-    }
+    std::string why;
+    if (!(api = rccl_api(&why))) return fail(INFLX_ERR_DEVICE, "RCCL (librccl.so) could not be loaded: %s", why.c_str());
     if ((rc = ensure_comms(mm, api))) return rc;
   } else if ((rc = ensure_push_streams(mm))) {
     return rc;
   }
+  // on every exit from here on -- errors included -- nothing may still be writing into the caller's buffers
+  auto drain_all = [&] {
+    for (size_t k = 0; k < world; ++k) {
+      (void)hipSetDevice(mm->dev[k]->device);
+      (void)hipStreamSynchronize(mm->dev[k]->side);
+      (void)hipStreamSynchronize(mm->dev[k]->stream);
+    }
+  };
   // AOS only: a device's slab is then one contiguous piece per parameter row of the (P, N0, N1, K) array
   const size_t row_bytes = N1 * point_bytes;
   for (size_t k = 0; k < world; ++k) {
@@ -2609,13 +2649,19 @@ int inflx_sweep_allgather_multi_ex(inflx_multi* mm, int op, const double* p, siz
       // parameter rows [p_begin, p_begin + p_count): one contiguous slice; the sweep writes it in place
       char* slice = mine + s.p_begin * N0 * row_bytes;
       rc = inflx_sweep_device(m, op, p + s.p_begin * n_p, s.p_count, n_p, slice, s.p_count * N0 * row_bytes, ss, N0, N1, 0, N0, INFLX_AOS, nullptr);
-      if (rc) return rc;
+      if (rc) {
+        drain_all();
+        return rc;
+      }
     } else {
       // grid rows [row_begin, row_begin + row_count) of every parameter row: one sweep per parameter row, each into its place
       for (size_t pr = 0; pr < P; ++pr) {
         char* slice = mine + (pr * N0 + s.row_begin) * row_bytes;
         rc = inflx_sweep_device(m, op, p + pr * n_p, 1, n_p, slice, s.row_count * row_bytes, ss, N0, N1, s.row_begin, s.row_count, INFLX_AOS, nullptr);
-        if (rc) return rc;
+        if (rc) {
+          drain_all();
+          return rc;
+        }
       }
     }
     if (gather == INFLX_GATHER_RCCL) continue;  // the collective below runs on every device's sweep stream, behind its sweep
@@ -2634,24 +2680,23 @@ int inflx_sweep_allgather_multi_ex(inflx_multi* mm, int op, const double* p, siz
     }
   }
   if (gather == INFLX_GATHER_RCCL) {
-    // In place (rccl.h: sendbuff == recvbuff + rank * sendcount): the device's own block is where the sweep put it.  Split along
-    // the parameter axis the whole (P, N0, N1, K) array is ONE gather; split along grid rows every parameter row is one (its
-    // blocks are contiguous within the row's (N0, N1, K) image) -- all of them, for all devices, fused in one group.
-    const ShardPlan s0 = shard_plan(P, N0, world, 0);
-    const size_t gathers = s0.axis == 0 ? 1 : P;
-    const size_t block_bytes = s0.axis == 0 ? s0.p_count * N0 * row_bytes : s0.row_count * row_bytes;
-    const size_t image_bytes = s0.axis == 0 ? P * N0 * row_bytes : N0 * row_bytes;
-    RCCL_TRY(api, api->GroupStart());
-    for (size_t q = 0; q < gathers; ++q)
-      for (size_t k = 0; k < world; ++k) {
-        char* base = static_cast<char*>(d_full[k]) + q * image_bytes;
-        const int r = api->AllGather(base + k * block_bytes, base, block_bytes / sizeof(double), kNcclFloat64, mm->comms[k], mm->dev[k]->stream);
-        if (r != 0) {
-          (void)api->GroupEnd();
-          return fail(INFLX_ERR_DEVICE, "ncclAllGather failed: %s", api->GetErrorString(r));
-        }
-      }
-    RCCL_TRY(api, api->GroupEnd());
+    // In place (rccl.h: sendbuff == recvbuff + rank * sendcount): the device's own block is where the sweep put it; all gathers of
+    // all devices fused in one group (rccl_gather_calls has the offsets).
+    int r = api->GroupStart();
+    if (r != 0) {
+      drain_all();
+      return fail(INFLX_ERR_DEVICE, "ncclGroupStart failed: %s", api->GetErrorString(r));
+    }
+    for (const GatherCall& c : rccl_gather_calls(P, N0, row_bytes, world)) {
+      char* base = static_cast<char*>(d_full[c.rank]);
+      r = api->AllGather(base + c.send_off, base + c.recv_off, c.count, kNcclFloat64, mm->comms[c.rank], mm->dev[c.rank]->stream);
+      if (r != 0) break;
+    }
+    const int rend = api->GroupEnd();
+    if (r != 0 || rend != 0) {
+      drain_all();  // the sweeps (and whatever part of the collective was enqueued) may still be running: wait before the caller gets its buffers back
+      return fail(INFLX_ERR_DEVICE, "%s failed: %s", r != 0 ? "ncclAllGather" : "ncclGroupEnd", api->GetErrorString(r != 0 ? r : rend));
+    }
   }
   // synchronous: every device holds the whole result when the call returns
   for (size_t k = 0; k < world; ++k) {

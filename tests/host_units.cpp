@@ -168,6 +168,33 @@ int main() {
     Reporter off(&big, 1e9, false);
     CHECK(!off.active());
   }
+  // ---- the in-place RCCL all-gather: (send, recv, count) per rank are the rank's shard_plan block inside its own full-size buffer
+  for (int trial = 0; trial < 400; ++trial) {
+    const size_t world = 1 + rnd() % 8;
+    const bool split_params = rnd() % 2;
+    // equal blocks are the entry point's precondition: the split axis divides by the device count
+    const size_t P = split_params ? world * (1 + rnd() % 5) : 1 + rnd() % (world > 1 ? world - 1 : 1);
+    const size_t N0 = split_params ? 1 + rnd() % 40 : world * (1 + rnd() % 9);
+    if (!split_params && P >= world) continue;
+    const size_t N1 = 1 + rnd() % 30, K = 6, row_bytes = N1 * K * sizeof(double);
+    const std::vector<GatherCall> calls = rccl_gather_calls(P, N0, row_bytes, world);
+    const ShardPlan s0 = shard_plan(P, N0, world, 0);
+    CHECK(s0.axis == (split_params ? 0 : 1));
+    CHECK(calls.size() == (s0.axis == 0 ? 1 : P) * world);
+    std::vector<char> covered(P * N0 * row_bytes, 0);  // every byte of the result is some rank's send block of some image, once
+    for (const GatherCall& c : calls) {
+      const ShardPlan s = shard_plan(P, N0, world, c.rank);
+      CHECK(s.axis == s0.axis);
+      // where the sweep put rank c.rank's block of image c.image (inflx_sweep_allgather_multi_ex: `slice`)
+      const size_t slice = s.axis == 0 ? s.p_begin * N0 * row_bytes : (c.image * N0 + s.row_begin) * row_bytes;
+      const size_t bytes = s.axis == 0 ? s.p_count * N0 * row_bytes : s.row_count * row_bytes;
+      CHECK(c.send_off == slice && c.count * sizeof(double) == bytes);
+      CHECK(c.send_off == c.recv_off + c.rank * c.count * sizeof(double));  // rccl.h: in place means sendbuff == recvbuff + rank * sendcount
+      CHECK(c.recv_off + world * bytes <= covered.size());                  // the image lies inside the buffer
+      for (size_t b = 0; b < bytes; ++b) CHECK(covered[c.send_off + b]++ == 0);
+    }
+    for (char v : covered) CHECK(v == 1);
+  }
   // ---- one host-thread budget per process: helpers in flight never exceed the budget once several devices are at work
   {
     // 16 CPUs, 8 devices (a GPU box's share, a whole node's GPUs): at most 16 helpers in flight, whichever kind

@@ -97,20 +97,21 @@ def test_two_rank_rehearsal(form):
     assert line["summary_sweep"]["non_nan"][1] == 2 * rows * 2048 * 2048
 
 
-def test_two_rank_rehearsal_degrades_when_the_block_does_not_fit():
-    """The first 8-GPU run must succeed unattended: when the default 64-row block cannot be allocated the block is halved,
-    in the same process and on every rank alike, and the line says which size ran.  Forced here with a 5 GB cap
-    (2048^2 x 6 x 8 B = 0.2 GB per row: 64 -> 32 -> 16 rows)."""
+def test_two_rank_rehearsal_sizes_the_block_to_the_free_hbm():
+    """The first 8-GPU run must succeed unattended: the resident block is sized UP FRONT from the HBM that is free on the ranks'
+    devices (bench.choose_rows_per_gpu), on every rank alike, and the line says which size ran.  Forced here with a 5 GB cap on the
+    free figure (2048^2 x 6 x 8 B = 0.2 GB per row: 64 requested, 24 fit)."""
     env = dict(os.environ, INFLX_BENCH_REHEARSE="1", HSA_ENABLE_IPC_MODE_LEGACY="0", INFLX_BENCH_MAX_BLOCK_GB="5")
     env.pop("WORLD_SIZE", None)
     proc = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--grid", "2048", "--steps", "3", "--warmup", "1"], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     line = _line(proc)
     cfg = line["config"]
-    assert cfg["rows_per_gpu_requested"] == 64 and cfg["parameter_rows_per_gpu"] == 16 and cfg["parameter_rows_total"] == 32
-    assert "do not fit" in proc.stderr and "trying 32" in proc.stderr and "trying 16" in proc.stderr
-    assert abs(line["value"] - 2 * 16 * 2048 * 2048 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-9
+    assert cfg["rows_per_gpu_requested"] == 64 and cfg["parameter_rows_per_gpu"] == 24 and cfg["parameter_rows_total"] == 48
+    assert cfg["hbm_free_gb_at_start"] > 0
+    assert "64 rows per GPU requested" in proc.stderr and "sweeping 24 rows per GPU" in proc.stderr
+    assert abs(line["value"] - 2 * 24 * 2048 * 2048 * 3 / (line["ms_per_step"] * 3e-3)) / line["value"] < 1e-9
     assert len(line["devices"]) == 2 and all("cuda:0" in d for d in line["devices"])
-    assert line["summary_sweep"]["non_nan"][1] == 2 * 16 * 2048 * 2048
+    assert line["summary_sweep"]["non_nan"][1] == 2 * 24 * 2048 * 2048
 
 
 def test_one_rank_through_rccl():

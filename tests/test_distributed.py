@@ -119,6 +119,68 @@ def test_two_gloo_ranks_shard_and_gather(case, tmp_path):
     assert axes == ({"param"} if case[1] >= 2 else {"rows"})
 
 
+def _config4_worker(rank, world, port, tmpdir):
+    """One of eight gloo ranks of BASELINE configs[4]'s plan: 512 parameter rows (L in linspace(0.2, 2.0, 512), bench.py's axis)
+    over 8 ranks = 64 rows each, the CPU oracle as the compute step on a reduced field grid."""
+    import torch
+    import torch.distributed as dist
+
+    import oracle
+    import workloads
+    from workloads import example_models
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    try:
+        spec = example_models.get("hyperbolic")
+        src, _ = oracle.emit_c_source(workloads.model_for("hyperbolic"), **spec.compiler_kwargs)
+        om = oracle.OracleModel(oracle.compile_c_model(src))
+        P, N0, N1 = 512, 6, 5
+        args = np.tile(np.asarray(spec.args, dtype=np.float64), (P, 1))
+        args[:, -1] = 0.2 + (2.0 - 0.2) * np.arange(P) / 511.0
+        pts = oracle.grid_points(spec.extent, N0, N1)
+
+        class Compute:
+            def allocates(self, outer):
+                return torch.full((*outer, N1, 6), -1.0, dtype=torch.float64)
+
+            def __call__(self, p_rows, row_begin, row_count, out=None):
+                assert (row_begin, row_count) == (0, N0) and len(p_rows) == P // world  # the parameter axis is what is split
+                block = np.stack([om.trajectory_sweep(oracle.OP.COMPLETE, p, pts).reshape(N0, N1, 6) for p in p_rows])
+                if out is None:
+                    return torch.from_numpy(block)
+                out.copy_(torch.from_numpy(block))
+                return out
+
+        sweep = ShardedSweep(Compute(), rank, world)
+        plan, full = sweep.run(args, N0, gather=True)
+        assert (plan.axis, plan.p_begin, plan.p_count, plan.row_begin, plan.row_count) == ("param", 64 * rank, 64, 0, N0)
+        assert tuple(full.shape) == (P, N0, N1, 6)
+        # every rank holds every row: spot-check a row of each rank's block against this rank's own oracle, and its own block in full
+        for r in range(world):
+            k = 64 * r + (7 * rank) % 64
+            assert np.array_equal(full[k].numpy(), om.grid_sweep(oracle.OP.COMPLETE, args[k], spec.extent, N0, N1), equal_nan=True), (rank, k)
+        _, local = sweep.run(args, N0, gather=False)
+        assert np.array_equal(local.numpy(), full[plan.p_begin : plan.p_begin + plan.p_count].numpy(), equal_nan=True)
+        combined = all_reduce_summary(numpy_summary(local.numpy()))
+        whole = numpy_summary(full.numpy())
+        assert np.array_equal(combined["min"], whole["min"]) and np.array_equal(combined["max"], whole["max"]) and np.array_equal(combined["count"], whole["count"])
+        assert int(combined["count"][1]) == P * N0 * N1  # epsilon_V is finite at every point of every row
+        open(os.path.join(tmpdir, f"ok_{rank}"), "w").write(f"{plan.p_begin}:{plan.p_count}")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_eight_gloo_ranks_on_the_plan_of_config4(tmp_path):
+    """BASELINE configs[4] (512 parameter rows over 8 GPUs) as far as a CPU container can rehearse it: eight gloo ranks, the
+    partition of plan_shard (64 rows each), the in-place all-gather of ShardedSweep and the three six-element all-reduces of the
+    summary -- the process-group code of the one-process-per-GPU form -- with the oracle standing in for the HIP sweep."""
+    import torch.multiprocessing as mp
+
+    port = _free_port()
+    mp.spawn(_config4_worker, args=(8, port, str(tmp_path)), nprocs=8, join=True)
+    assert sorted(open(tmp_path / f"ok_{r}").read() for r in range(8)) == sorted(f"{64 * r}:64" for r in range(8))
+
+
 # ---- the same two-rank exercise with the HIP sweep as the local compute step ---------------------------
 # (GPU box: both ranks use the one visible GPU and exchange CPU tensors over gloo, because RCCL refuses
 # two ranks per device; partition, per-rank launch through the C ABI, gather and summary are the product's)

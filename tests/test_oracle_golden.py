@@ -15,7 +15,7 @@ from conftest import COMPILERS, MODELS, compare, golden, golden_key, oracle_mode
 import oracle
 from oracle import OP
 
-GRID_TAGS = {"hyperbolic": ("g16", "g64", "ragged"), "doc": ("g16", "g64", "neg"), "angular": ("g16", "g64", "inner"), "egno": ("g16", "g64"), "d5": ("g16", "g64")}
+GRID_TAGS = {"hyperbolic": ("g16", "g64", "ragged", "off"), "doc": ("g16", "g64", "neg"), "angular": ("g16", "g64", "inner"), "egno": ("g16", "g64"), "d5": ("g16", "g64", "off")}
 
 
 def test_both_reference_compilers_are_present():

@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 
 STRICT = ("hyperbolic",)  # additionally asserted to the literal 1e-10 bar, no allowance, on every grid
 STRICT_GOLDEN = ("hyperbolic", "doc")  # ... and on the golden grids (doc measures 1.6e-13 there)
-GRID_TAGS = {"hyperbolic": ("g16", "g64", "ragged"), "doc": ("g16", "g64", "neg"), "angular": ("g16", "g64", "inner"), "egno": ("g16", "g64"), "d5": ("g16", "g64")}
+GRID_TAGS = {"hyperbolic": ("g16", "g64", "ragged", "off"), "doc": ("g16", "g64", "neg"), "angular": ("g16", "g64", "inner"), "egno": ("g16", "g64"), "d5": ("g16", "g64", "off")}
 
 
 def golden_refs(g, tag, key):
@@ -1106,8 +1106,10 @@ def test_plain_c_client_of_the_c_abi(gpu_lib, tmp_path):
     _, core_only = workloads.artifact_for("doc")
     proc = subprocess.run([str(exe), core_only.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 7 and f"({_native.ERR_SYMBOL})" in proc.stderr and '"consistency"' in proc.stderr and core_only.shared_object_path + ".consistency" in proc.stderr, (proc.returncode, proc.stderr)
-    # (2) the group next to the artefact, as `<artefact>.consistency`: the library loads it on demand
+    # (2) the groups next to the artefact, as `<artefact>.<group>` (the client goes on to the summary sweeps: "stats"): the library loads
+    # each on demand
     assert core_only.ensure_group("consistency") == core_only.shared_object_path + ".consistency"
+    assert len(core_only.ensure_all_groups()) == 8
     proc = subprocess.run([str(exe), core_only.shared_object_path, *tail], capture_output=True, text=True, timeout=300)
     assert proc.returncode == 0, (proc.returncode, proc.stdout, proc.stderr)
     first = np.fromfile(out, dtype=np.float64)

@@ -108,3 +108,31 @@ def test_default_bound_follows_the_machine_and_release_empties_the_pool(monkeypa
     b = pool.result_array((77, 13, 6))  # a fresh mapping, usable as ever
     b[...] = 2.0
     assert float(b.sum()) == 2.0 * 77 * 13 * 6 and (addr or True)
+
+
+def test_memory_limits_are_found_on_every_level_up_to_the_root(tmp_path):
+    """A memory limit on an intermediate ancestor (a systemd slice, SLURM's job / step levels) bounds the pool too: the walk goes from
+    the process's own cgroup up to the root and keeps every limit; "max" and the v1 "unlimited" sentinel are none."""
+    from inflatox_amd import _result_pool as rp
+
+    assert list(rp._levels("/a/b/c")) == ["/a/b/c", "/a/b", "/a", ""] and list(rp._levels("/")) == [""]
+    v2, v1 = tmp_path / "v2", tmp_path / "v1"
+    (v2 / "job_7" / "step_0" / "task_3").mkdir(parents=True)
+    (v2 / "memory.max").write_text("max\n")
+    (v2 / "job_7" / "memory.max").write_text(str(6 << 30) + "\n")  # the job's limit: two levels above the process
+    (v2 / "job_7" / "step_0" / "memory.max").write_text("max\n")
+    (v2 / "job_7" / "step_0" / "task_3" / "memory.max").write_text(str(64 << 30) + "\n")
+    (v1 / "slurm" / "uid_1" / "job_9").mkdir(parents=True)
+    (v1 / "memory.limit_in_bytes").write_text(str(rp._V1_UNLIMITED) + "\n")
+    (v1 / "slurm" / "memory.limit_in_bytes").write_text(str(48 << 30) + "\n")
+    (v1 / "slurm" / "uid_1" / "job_9" / "memory.limit_in_bytes").write_text(str(rp._V1_UNLIMITED) + "\n")
+    proc = tmp_path / "cgroup"
+    proc.write_text("0::/job_7/step_0/task_3\n5:cpu,memory:/slurm/uid_1/job_9\n3:cpuset:/\n")
+    limits = rp.cgroup_memory_limits(str(proc), str(v2), str(v1))
+    assert sorted(limits) == [6 << 30, 48 << 30, 64 << 30] and min(limits) == 6 << 30
+    # inside a container the process's path does not exist below the mount: the root file still counts
+    proc.write_text("0::/docker/abcdef\n")
+    (v2 / "memory.max").write_text(str(32 << 30) + "\n")
+    assert rp.cgroup_memory_limits(str(proc), str(v2), str(v1)) == [32 << 30]
+    # no /proc/self/cgroup at all: the roots
+    assert rp.cgroup_memory_limits(str(tmp_path / "nothing"), str(v2), str(v1)) == [32 << 30]

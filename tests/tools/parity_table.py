@@ -29,13 +29,21 @@ def main(src, dst):
                 cell[k] = cell.get(k, 0) + int(r.get(k, 0) or 0)
             cell["max_rel"] = max(cell.get("max_rel", 0.0), r.get("max_rel", 0.0) or 0.0)
         else:
-            cell["max_excluded"] = max(cell.get("max_excluded", 0.0), r.get("excluded", 0.0))
+            if r.get("excluded", 0.0) >= cell.get("max_excluded", 0.0):
+                cell["max_excluded"], cell["max_excluded_at"], cell["max_excluded_cap"] = r.get("excluded", 0.0), r["what"], r.get("excluded_cap")
             cell["nan_mismatch_at_flaky_points"] = cell.get("nan_mismatch_at_flaky_points", 0) + int(r.get("nan_mismatch_at_flaky_points", 0) or 0)
+            # the GPU against this build in plain relative terms (round 6): values above the literal 1e-10, the largest relative difference
+            cell["above_1e-10"] = cell.get("above_1e-10", 0) + int(r.get("above_1e-10", 0) or 0)
+            cell["max_rel"] = max(cell.get("max_rel", 0.0), r.get("max_rel", 0.0) or 0.0)
+            if "/off/" in r["what"] or r["what"].endswith("/off"):
+                cell["excluded_on_the_off_grid"] = max(cell.get("excluded_on_the_off_grid", 0.0), r.get("excluded", 0.0))
     out = {
         "what": "per model and build: GPU vs the gcc-built reference, GPU vs the clang-built reference (worst |gpu - ref| / allowance over every "
         "comparison of the -m gpu suite; <= 1 passes; NaN and Inf patterns are asserted exactly at every point whose NaN-ness the reference "
         "itself settles), and the reference's two builds against each other under the same allowance (nothing asserted: a ratio above 1 means "
-        "the reference differs from itself by more than the GPU may differ from it)",
+        "the reference differs from itself by more than the GPU may differ from it).  above_1e-10 / max_rel: compared finite values that differ by "
+        "more than the literal 1e-10 relative, and the largest relative difference -- for the GPU against each build and for the two builds "
+        "against each other.  KAPPA and the exclusion caps in force: tests/tolerance.py",
         "table": table,
         "records": len(recs),
     }
