@@ -217,19 +217,16 @@ def device_count() -> int:
     return n.value if rc == OK else 0
 
 
-def _ensure_group(lib, handles, artefact_path: str, group: str) -> None:
+def _ensure_group(lib, handles, art, group: str) -> None:
     """Make the kernels of ``group`` available on every handle in ``handles``: nothing to do when they are loaded; otherwise the
-    artefact that owns ``artefact_path`` builds the group (one hipcc step on first use, ``CompilationArtifact.ensure_group``) and it
+    artefact ``art`` the handles were opened from builds the group (one hipcc step on first use, ``CompilationArtifact.ensure_group``) and it
     is attached.  An artefact from elsewhere (a bare file) is left to ``libinflx_hip.so``, which looks for ``<artefact>.<group>``
     itself and says what is missing."""
-    from .compiler import KERNEL_GROUPS, artefact_for_path
+    from .compiler import KERNEL_GROUPS
 
     bit = KERNEL_GROUPS[group]
     pending = [h for h in handles if not (int(lib.inflx_groups(h)) & bit)]
-    if not pending:
-        return
-    art = artefact_for_path(artefact_path)
-    if art is None:
+    if not pending or art is None:
         return
     path = art.ensure_group(group)
     if path is None:
@@ -248,6 +245,11 @@ class InflatoxDevLib:
         self._h = handle
         self._lib = lib
         self.path = artefact_path
+        # the artefact this file is the core object of (None: a bare file): it builds the kernel groups of the other operations on
+        # first use, so the handle keeps it alive for as long as it lives itself
+        from .compiler import artefact_for_path
+
+        self._artefact = artefact_for_path(artefact_path)
         self.device = int(device)
         self.n_fields = int(lib.inflx_n_fields(handle))
         self.n_parameters = int(lib.inflx_n_parameters(handle))
@@ -269,7 +271,7 @@ class InflatoxDevLib:
 
     def _need(self, group: str) -> None:
         """The kernel group of the operation about to run (built and attached on first use; see ``_ensure_group``)."""
-        _ensure_group(self._lib, [self._h], self.path, group)
+        _ensure_group(self._lib, [self._h], self._artefact, group)
 
     @property
     def groups(self) -> int:
@@ -519,6 +521,9 @@ class InflatoxMultiLib:
         self._h = handle
         self._lib = lib
         self.path = artefact_path
+        from .compiler import artefact_for_path
+
+        self._artefact = artefact_for_path(artefact_path)
         self.n_devices = int(lib.inflx_multi_device_count(handle))
         self.devices = [int(lib.inflx_device_of(lib.inflx_multi_handle(handle, k))) for k in range(self.n_devices)]
         first = lib.inflx_multi_handle(handle, 0)
@@ -537,7 +542,7 @@ class InflatoxMultiLib:
 
     def _need(self, group: str) -> None:
         handles = [self._lib.inflx_multi_handle(self._h, k) for k in range(self.n_devices)]
-        _ensure_group(self._lib, handles, self.path, group)
+        _ensure_group(self._lib, handles, self._artefact, group)
 
     def complete_analysis(self, p, out, start_stop, progress=False, threads=0):
         """``libinflx_rs.complete_analysis(lib, p, out, start_stop, progress, threads)`` (anguelova.rs:458) on the handle's

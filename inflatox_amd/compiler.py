@@ -402,6 +402,15 @@ class Compiler:
       bit, which is why the default build does not take it; a wavefront all of whose points qualify skips the ~55
       instructions of the tangent (doc 4096^2: 0.237 -> 0.210 ms).
 
+    * ``contraction`` (default ``"expression"``, since round 6): a product that is a direct operand of a sum is spelled out in the sum's
+      own statement (``staging.Stager.sum_operand``), so that hipcc -- clang with ``-ffp-contract=on`` -- fuses the multiply-adds the
+      reference's compiler (``zig cc`` = clang, same flag) fuses in the reference's one-expression C functions.  With ``"statement"``
+      (rounds 1-5) a product the stager has made a (row / shared) variable of is added already rounded, which is what ``gcc -std=c17``
+      does with the reference's C everywhere.  Measured on MI355X (profiles/r06_contraction.json): on the reference-generated golden
+      grids D5's values bit-equal to the clang build rise from 11 716 to 12 696 of 19 040 (gcc build: 12 725 -> 11 925), values off by
+      more than 1e-10 from the clang build fall from 259 to 38, and at all 10 + 25 values where the two builds disagree about NaN the
+      GPU now sides with clang (before: with gcc at every one); angular 9 793 -> 12 038 of 17 240; EGNO (``cse=True``: the reference's
+      own statements end the fusion) and doc unchanged; device time within +-2 %.
     * ``kernel_groups`` (default ``"core"``): which kernel groups ``compile()`` builds into the artefact's code object.  ``"core"``: what
       ``complete_analysis`` (grid and on-trajectory) and the basis validation need -- ONE hipcc step of 1-2.5 s (D5: 2.2 s), like the
       reference's one ``zig cc`` step; every other operation's group (``KERNEL_GROUPS``) is built when first used, 1.5-2.5 s each
@@ -477,14 +486,18 @@ class Compiler:
         sample=None,
         quick_sqrt: bool | None = None,
         kernel_groups="core",
+        contraction: str = "expression",
     ):
         # what CompilationArtifact.profile_guided needs to compile the same model again with a measured re-association
         self._init_kwargs = dict(output_path=None, cleanup=cleanup, silent=silent, link_gsl=link_gsl, cse=cse, max_cses=max_cses, compiler_flags=compiler_flags,
                                  staged=staged, exact_constants=exact_constants, hoist_reciprocals=hoist_reciprocals, share_reciprocals=share_reciprocals, quick_sqrt=quick_sqrt,
-                                 kernel_groups=kernel_groups)
+                                 kernel_groups=kernel_groups, contraction=contraction)
         # link_gsl: nothing is linked here -- the Bessel functions the reference takes from GSL are device
         # functions of this package (csrc/inflx_sf.h, integer orders); the flag is recorded in USE_GSL
         self.gsl = bool(link_gsl)
+        if contraction not in ("statement", "expression"):
+            raise ValueError('contraction must be "statement" or "expression"')
+        self.contraction = contraction
         if isinstance(kernel_groups, str):
             if kernel_groups not in ("core", "all"):
                 raise ValueError('kernel_groups must be "core", "all" or an iterable of group names')
@@ -670,6 +683,7 @@ class Compiler:
                 hoist_reciprocals=hoist,
                 share_point_reciprocals=self.share_reciprocals,
                 quick_sqrt=(hoist is True or hoist == 1) if self.quick_sqrt is None else bool(self.quick_sqrt),
+                contract_products=self.contraction == "expression",
             )
 
         if self.hoist_reciprocals is None:

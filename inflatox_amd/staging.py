@@ -247,9 +247,13 @@ class HIPInflatoxPrinter(C99CodePrinter):
             terms = self.stager.hoist_prefix(self.stager.group_terms(terms), "+")
         prec = precedence(expr)
         parts = []
-        for term in terms:
-            t = self._print(term)
-            named = self.stager is not None and self.stager.is_named(term)
+        for k, term in enumerate(terms):
+            if self.stager is not None:
+                # (clang fuses ONE operand of an addition, the left one first: in ((t0 + t1) + t2) ... the product t1 stays a rounded
+                # value when t0 is a product itself)
+                t, named = self.stager.sum_operand(term, fusable=not (k == 1 and self.stager.is_plain_product(terms[0])))
+            else:
+                t, named = self._print(term), False
             if t.startswith("-") and not (term.is_Add and not named):
                 sign, t = "-", t[1:]
             else:
@@ -310,7 +314,7 @@ class Stager:
     switch that mirrors the reference's five separate C functions.
     """
 
-    def __init__(self, functions, x0, x1, names, staged=True, regroup=False, hoist_reciprocals=False, shared_point_dens=()):
+    def __init__(self, functions, x0, x1, names, staged=True, regroup=False, hoist_reciprocals=False, shared_point_dens=(), contract_products=False):
         """``functions``: one ``(replacements, [expressions])`` pair per generated C function of the
         reference (five scalar functions and the two-component basis vector ``v``), where
         ``replacements`` is the (possibly empty) list of ``(symbol, definition)`` pairs the
@@ -318,6 +322,8 @@ class Stager:
         sys.setrecursionlimit(max(sys.getrecursionlimit(), 50000))
         self.regroup = regroup
         self.staged = staged
+        # a product that is a direct operand of a sum keeps its LAST multiplication in the statement of the sum (see sum_operand)
+        self.contract_products = bool(contract_products) and staged
         # "inline": the hoisted quotients check themselves and fall back to the IEEE division on the spot (one point stage,
         # no `ok` bookkeeping); True: the quick / IEEE pair of point stages with the row redone when a quotient is irregular
         self.hoist_inline = hoist_reciprocals == "inline" and staged
@@ -444,6 +450,39 @@ class Stager:
         if m != self._ctx or self.refs[e] >= 2:
             return self._variable(e, m)
         return self.printer.print_node(e)
+
+    @staticmethod
+    def is_plain_product(term) -> bool:
+        """Does the C text of ``term`` end in a multiplication (a*b, -a*b*c, 2*x; not a*b/c, not a function call)?"""
+        if isinstance(term, _Group) or not term.is_Mul:
+            return False
+        _, num, den, _ = split_product(term)
+        return not den and len(num) >= 2
+
+    def sum_operand(self, term, fusable=True):
+        """(C text, is it a stage variable?) of one operand of a sum.
+
+        ``contract_products`` (``Compiler(contraction="expression")``): the reference's C holds every model function as ONE expression,
+        and the compiler it is built with -- ``zig cc`` = clang, ``-ffp-contract=on`` -- turns ``x*y + z`` into fma(x, y, z) wherever a
+        multiplication is a direct operand of an addition in that expression (python/inflatox/compiler.py:299-310,575-584).  hipcc is
+        the same clang with the same rule, but the rule ends at a statement: a product that the stager has made a variable of -- shared
+        by several uses, or evaluated once per row -- reaches the sum already rounded.  Here such a product is spelled out in the sum's
+        own statement instead, its leading factors as the (stage) value the reference computes on the way and its LAST multiplication in
+        place, so that the compiler fuses exactly what clang fuses in the reference's text: ``r_12 + p_4`` becomes ``r_1*r_2 + p_4``.
+        Same instruction count per point (an fma for an add), a few more row values read."""
+        if self.contract_products and fusable and not isinstance(term, _Group) and term.is_Mul and term not in self.local:
+            sign, num, den, _ = split_product(term)
+            m = self.mask(term)
+            # only a product that would arrive as a variable: one of an earlier stage, or one shared by several uses
+            would_be_named = term.free_symbols and (m != self._ctx or self.refs[term] >= 2 or term in self.named)
+            if would_be_named and not den and len(num) >= 2:
+                if m == self._ctx:
+                    return self.printer.print_node(term), False  # (its leading factors of earlier stages still become one stage value)
+                prec = precedence(term)
+                head, last = num[:-1], num[-1]
+                head_text = self.value(_Group("*prefix", head)) if len(head) >= 2 else self.printer._operand(head[0], prec)
+                return f"{sign}{head_text}*{self.printer._operand(last, prec)}", False
+        return self.value(term), self.is_named(term)
 
     def group_terms(self, items):
         """Fast mode only (``regroup``): within a sum printed in stage ctx, the terms of each lower class
@@ -677,9 +716,8 @@ class Stager:
 
     def _sum_text(self, terms):
         parts = []
-        for term in terms:
-            t = self.printer._print(term)
-            named = self.is_named(term)
+        for k, term in enumerate(terms):
+            t, named = self.sum_operand(term, fusable=not (k == 1 and self.is_plain_product(terms[0])))
             if t.startswith("-") and not (term.is_Add and not named):
                 sign, t = "-", t[1:]
             else:
@@ -699,6 +737,7 @@ def emit_stage_header(
     hoist_reciprocals: bool = False,
     share_point_reciprocals: bool = False,
     quick_sqrt: bool | None = None,
+    contract_products: bool = False,
 ):
     """Return (header text, info dict) for the model.
 
@@ -736,12 +775,12 @@ def emit_stage_header(
         else:
             functions.append(([], [e]))
     functions.append(cse_vector(basis_v) if cse_vector is not None else ([], basis_v))
-    st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals)
+    st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals, contract_products=contract_products)
     if hoist_reciprocals and share_point_reciprocals:
         # second pass: per-point denominators that serve several quotients get one shared reciprocal
         several = [text for text, n in st.point_den_counts.items() if n >= 2]
         if several:
-            st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals, shared_point_dens=several)
+            st = Stager(functions, x0, x1, names, staged=staged, regroup=regroup, hoist_reciprocals=hoist_reciprocals, shared_point_dens=several, contract_products=contract_products)
     range_flags = st.finish_range_flags()
 
     idx = {m: {n: k for k, n in enumerate(st.exports[m])} for m in (U, R, C)}

@@ -14,10 +14,16 @@ _DP = C.POINTER(C.c_double)
 
 
 class HostTwin:
-    def __init__(self, header_text: str, contract: str = "off"):
+    def __init__(self, header_text: str, contract: str = "off", cxx: str = "g++"):
+        """``cxx``: the host compiler; "clang++" (the ROCm image's) understands ``contract="on"`` -- fusion within a statement, the rule
+        hipcc applies to the kernels and `zig cc` to the reference's C -- which g++ reads as "off"."""
+        if cxx == "clang++":
+            import shutil
+
+            cxx = shutil.which("clang++") or "/opt/rocm/lib/llvm/bin/clang++"
         # INFLX_TEST_SANITIZE=1 (manual runs under LD_PRELOAD=libasan.so): the generated stage code and csrc/inflx_ops.h under ASan + UBSan
         sanitize = ["-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-g"] if os.environ.get("INFLX_TEST_SANITIZE") else []
-        tag = hashlib.sha1((header_text + contract + " ".join(sanitize)).encode()).hexdigest()[:16]
+        tag = hashlib.sha1((header_text + contract + cxx + " ".join(sanitize)).encode()).hexdigest()[:16]
         d = os.path.join(tempfile.gettempdir(), "inflx_host_twin")
         os.makedirs(d, exist_ok=True)
         hdr = os.path.join(d, f"{tag}.h")
@@ -26,7 +32,7 @@ class HostTwin:
             with open(hdr, "w") as fh:
                 fh.write(header_text)
             cmd = [
-                "g++", "-O2", "-std=c++17", "-fPIC", "-shared", f"-ffp-contract={contract}", "-fno-fast-math", "-Wno-unknown-pragmas", *sanitize,
+                cxx, "-O2", "-std=c++17", "-fPIC", "-shared", f"-ffp-contract={contract}", *(["-mfma"] if contract != "off" else []),  # (a fused multiply-add needs the instruction) "-fno-fast-math", "-Wno-unknown-pragmas", *sanitize,
                 f"-I{os.path.join(ROOT, 'inflatox_amd', 'csrc')}", f'-DINFLX_MODEL_HEADER="{hdr}"',
                 os.path.join(HERE, "host_twin.cpp"), "-o", so + ".tmp",
             ]  # fmt: skip

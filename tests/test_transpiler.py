@@ -381,3 +381,45 @@ def test_an_artefact_can_rebuild_itself_profile_guided():
 
     with pytest.raises(ValueError):
         CompilationArtifact({}, "/nonexistent", 2, 0, auto_cleanup=False).profile_guided(spec.args, spec.extent)
+
+
+@pytest.mark.parametrize("name", ["angular", "d5"])
+def test_expression_contraction_follows_the_references_clang_build(name):
+    """The reference compiles its C with `zig cc` = clang, which fuses a*b + c inside an expression; the kernels are compiled by the
+    same clang with the same rule, statement by statement.  With Compiler(contraction="expression") (the default since round 6) a
+    product the stager made a variable of is spelled out in the statement of the sum it feeds, so that the same multiply-adds fuse:
+    the generated header, built for the host by clang with -ffp-contract=on, reproduces more of the clang-built reference's bits than
+    the "statement" style does, fewer of the gcc-built one's -- and where the two builds of the reference disagree about NaN (D5, on
+    its singular lines) it takes clang's side at every such value, where the "statement" style took gcc's."""
+    import shutil
+
+    from host_twin import HostTwin
+
+    if not (shutil.which("clang++") or os.path.exists("/opt/rocm/lib/llvm/bin/clang++")):
+        pytest.skip("no clang++ for a host build with -ffp-contract=on")
+    spec = example_models.get(name)
+    g = golden(name)
+    tally = {}
+    for style in ("statement", "expression"):
+        comp = Compiler(workloads.model_for(name), silent=True, contraction=style, **spec.compiler_kwargs)
+        twin = HostTwin(comp._generate_hip_header(), contract="on", cxx="clang++")
+        t = dict(eq_gcc=0, eq_clang=0, like_gcc=0, like_clang=0, disagreements=0)
+        for tag in ("g16", "g64"):
+            n0, n1 = (int(v) for v in g[f"{tag}_shape"])
+            got = twin.grid(4, g["args"], g[f"{tag}_extent"], n0, n1)  # INFLX_OP_RAW
+            a, b = g[f"{tag}_raw"], g[f"{tag}_raw_clang"]
+            same = lambda x, y: (x == y) | (np.isnan(x) & np.isnan(y))  # noqa: E731
+            nd = np.isnan(a) != np.isnan(b)
+            t["eq_gcc"] += int(same(got, a).sum())
+            t["eq_clang"] += int(same(got, b).sum())
+            t["disagreements"] += int(nd.sum())
+            t["like_gcc"] += int((np.isnan(got) == np.isnan(a))[nd].sum())
+            t["like_clang"] += int((np.isnan(got) == np.isnan(b))[nd].sum())
+        tally[style] = t
+    st, ex = tally["statement"], tally["expression"]
+    assert ex["eq_clang"] > st["eq_clang"] and ex["eq_gcc"] < st["eq_gcc"], tally
+    assert ex["eq_clang"] > ex["eq_gcc"], tally
+    if ex["disagreements"]:
+        assert ex["like_clang"] == ex["disagreements"] and ex["like_gcc"] == 0, tally
+        assert st["like_gcc"] == st["disagreements"], tally
+    assert Compiler(workloads.model_for(name), silent=True).contraction == "expression"

@@ -54,7 +54,7 @@ EXCLUDED_CAP_BY_GRID = {
     ("hyperbolic", "hyperbolic/g16"): 0.07,  # 16 x 16 over (-1, 1): row 8 is x0 = 0 exactly, v11 = -inf there and everything derived from it (3.1 % observed)
     ("hyperbolic", "hyperbolic/"): 0.04,  # grids over the README extent with an even row count contain that row (1 / N0 of the values; 64 x 48: 1.6 %)
     ("d5", "d5/g16"): 0.12,  # every second column of the 16 x 16 golden grid is ON a singular line theta = k pi/2 (9.6 % observed)
-    ("d5", "d5/g64"): 0.03,  # 64 x 48: columns 0, 12, 24, 36 (1.2 % observed)
+    ("d5", "d5/g64"): 0.05,  # 64 x 48: columns 0, 12, 24, 36 (1.2 % of the model values, 3.2 % of the derived outputs observed)
     ("d5", "d5/off"): 0.01,  # the grid that misses them
     ("d5", "d5/"): 0.06,  # other grids over the model's extent (0, 36) x (0, 4 pi): the row r = 0 and the columns theta = k pi
     ("doc", "doc/"): 0.01,  # the r = 0 row

@@ -29,7 +29,7 @@ def model_for(name: str) -> InflationModel:
 
 def _experiment_switches() -> dict:
     """Experiment switches for runs of the whole parity suite / the probes under another build of the example models
-    (profiles/r03_experiments.txt): ``INFLX_REGROUP=1`` or a comma list of value names (``V,v00,g``), ``INFLX_TAN_SHORTCUT=T``.
+    (profiles/r03_experiments.txt): ``INFLX_REGROUP=1`` or a comma list of value names (``V,v00,g``), ``INFLX_TAN_SHORTCUT=T``, ``INFLX_CONTRACTION=expression``.
     They live here, in test / bench infrastructure: ``Compiler`` itself reads no environment variable."""
     import os
 
@@ -39,6 +39,9 @@ def _experiment_switches() -> dict:
         if env == "auto":
             raise ValueError('INFLX_REGROUP=auto: the measured choice needs a sample; use artifact_for(name, tuned=True)')
         out["regroup"] = bool(int(env)) if env.isdigit() else tuple(env.split(","))
+    env = os.environ.get("INFLX_CONTRACTION", "")  # "expression": Compiler(contraction="expression"), the round-6 measurement
+    if env:
+        out["contraction"] = env
     env = os.environ.get("INFLX_TAN_SHORTCUT", "")
     if env:
         out["tan_shortcut"] = float(env)
