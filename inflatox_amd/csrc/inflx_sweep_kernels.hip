@@ -512,6 +512,15 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
   // and coefficients loaded once, R rows restaged behind a barrier, wave slots held across the hand-over -- was measured in round 5,
   // bit-identical results: D5 4096^2 x 32 14.06 ms with 1 tile, 14.44 / 14.84 / 15.83 with 2 / 4 / 8; EGNO x 32 13.10 / 13.05 /
   // 13.13 / 13.43; doc x 16 3.47 / 3.47 / 3.44 / 3.49 -- profiles/r05_experiments.txt section 4.)
+#ifdef INFLX_EXPERIMENT_R_SCALAR
+  // (A/B experiment, profiles/r06_experiments.txt: the row's R values straight from the stage table through the scalar cache -- the
+  // address is wave-uniform and the table constant for the kernel's lifetime -- instead of LDS broadcasts into vector registers)
+  typedef const double __attribute__((address_space(4))) inflx_cdouble;
+  const double* __restrict__ rbase = rtab + (uint64_t)blockIdx.y * tile_rows * kNRs;
+#define INFLX_ROW_VALUES(r) ((const double*)(inflx_cdouble*)(rbase + (uint64_t)(r) * kNRs))
+#else
+#define INFLX_ROW_VALUES(r) (Rs[r])
+#endif
   uint64_t redo = 0;
   int streak = 0;  // consecutive irregular rows (wave-uniform)
   for (int r = 0; r < nrows; ++r) {  // (unrolling by 2 was measured: no gain, scripts/tile_tuning.py)
@@ -524,9 +533,9 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     InflxModelValues mv;
     bool ok = true;
 #if INFLX_HAS_QUICK_POINT
-    inflx_stage_point_quick(x0, x1, A, U, Rs[r], C, mv, ok);
+    inflx_stage_point_quick(x0, x1, A, U, INFLX_ROW_VALUES(r), C, mv, ok);
 #else
-    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+    inflx_stage_point(x0, x1, A, U, INFLX_ROW_VALUES(r), C, mv);
 #endif
     fill_v01<OP>(mv, x0, x1, A);
     double o[K];
@@ -548,15 +557,16 @@ __device__ __forceinline__ void sweep_tile(const InflxSweepArgs& a) {
     const double x0 = inflx_coord(a.row_begin + row, a.dx0, a.x0a);
     InflxModelValues mv;
 #if INFLX_HAS_QUICK_POINT
-    inflx_stage_point_ieee(x0, x1, A, U, Rs[r], C, mv);
+    inflx_stage_point_ieee(x0, x1, A, U, INFLX_ROW_VALUES(r), C, mv);
 #else
-    inflx_stage_point(x0, x1, A, U, Rs[r], C, mv);
+    inflx_stage_point(x0, x1, A, U, INFLX_ROW_VALUES(r), C, mv);
 #endif
     fill_v01<OP>(mv, x0, x1, A);
     double o[K];
     apply_op<OP, kTable>(mv, o, a.accuracy, kc);
     emit(o, row);
   }
+#undef INFLX_ROW_VALUES
   if constexpr (STATS) stat_flush(acc, a.stats);
 }
 

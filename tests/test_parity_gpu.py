@@ -925,11 +925,18 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
     # the third grid starts exactly at x1 = 0 and x0 = 0 where the models have them in range: structural zeros (a
     # whole column of zero numerators) and the wavefronts that give up on the quick stage after two irregular rows
     zero = np.array([[0.0, spec.extent[1]], [0.0, spec.extent[3]]])
+    # round 6: the same quotients as self-checking ones in ONE point stage (hoist_reciprocals="inline": a wavefront in which a lane's
+    # quotient is irregular divides those lanes the IEEE way on the spot) -- the same bits again
+    _, art_i = workloads.artifact_for(name, hoist_reciprocals="inline")
+    lib_i = gpu_lib.InflatoxDevLib(art_i.shared_object_path)
+    assert art_i.stage_info["hoisted_quotients"] == art_i.stage_info["shared_quotients"] == 0
+    assert art_i.stage_info["inline_quotients"] >= (9 if name in ("d5", "egno") else 0)
     for extent, n0, n1 in ((ss, 300, 520), (wide, 257, 191), (zero, 130, 700)):
         for op in (gpu_lib.OP_COMPLETE, gpu_lib.OP_RAW, gpu_lib.OP_CONSISTENCY):
             a = lib.sweep_host(op, spec.args, extent, n0, n1)
             b = lib_h.sweep_host(op, spec.args, extent, n0, n1)
             assert np.array_equal(a, b, equal_nan=True), (name, op, n0, n1)
+            assert np.array_equal(a, lib_i.sweep_host(op, spec.args, extent, n0, n1), equal_nan=True), (name, "inline", op, n0, n1)
     s0, s1 = lib.sweep_stats(spec.args, ss, 300, 520), lib_h.sweep_stats(spec.args, ss, 300, 520)
     assert all(np.array_equal(s0[k], s1[k]) for k in ("min", "max", "count"))
     # Parameters that push the quick stage out of its validity range -- a parameter that is exactly zero (whole
@@ -942,6 +949,7 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
             a = lib.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 70, 130)
             b = lib_h.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 70, 130)
             assert np.array_equal(a, b, equal_nan=True), (name, k, value)
+            assert np.array_equal(a, lib_i.sweep_host(gpu_lib.OP_COMPLETE, args, ss, 70, 130), equal_nan=True), (name, "inline", k, value)
 
 
 def test_open_close_cycles_do_not_leak_and_models_coexist(gpu_lib):

@@ -275,6 +275,23 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
         assert np.array_equal(a.grid(op, g["args"], g["g64_extent"], n0, n1), b.grid(op, g["args"], g["g64_extent"], n0, n1), equal_nan=True)
     ext = example_models.get(name).extent
     assert np.array_equal(a.grid(0, g["args"], ext, 150, 130), b.grid(0, g["args"], ext, 150, 130), equal_nan=True)
+    # round 6: the same quotients checking themselves in ONE point stage (hoist_reciprocals="inline")
+    inline, with_i = header_for(name, hoist_reciprocals="inline")
+    assert "INFLX_DIVI(" in with_i and "inflx_stage_point_quick" not in with_i and "#define INFLX_HAS_QUICK_POINT 0" in with_i
+    assert inline.stage_info["inline_quotients"] == plain.stage_info["hoisted_quotients"] and inline.stage_info["quick_square_roots"] == 0
+    c = HostTwin(with_i)
+    for op in (4, 0):
+        assert np.array_equal(c.grid(op, g["args"], g["g64_extent"], n0, n1), b.grid(op, g["args"], g["g64_extent"], n0, n1), equal_nan=True)
+    assert np.array_equal(c.grid(0, g["args"], ext, 150, 130), b.grid(0, g["args"], ext, 150, 130), equal_nan=True)
+
+
+def test_compiler_rejects_unknown_round6_options():
+    m = workloads.model_for("hyperbolic")
+    for bad in (dict(kernel_groups="everything"), dict(kernel_groups=["core", "nonsense"]), dict(contraction="fast")):
+        with pytest.raises(ValueError):
+            Compiler(m, silent=True, **bad)
+    assert Compiler(m, silent=True, kernel_groups=["raw", "stats"]).kernel_groups == 1 | 64 | 2
+    assert Compiler(m, silent=True, kernel_groups="all").kernel_groups == 511 and Compiler(m, silent=True).kernel_groups == 1
 
 
 def test_abs_quotient_sign_identity_used_by_the_epilogue():
