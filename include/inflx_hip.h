@@ -40,8 +40,22 @@ typedef enum inflx_status {
   INFLX_ERR_DEVICE = 5,  /* HIP runtime failure (no counterpart)   -> SystemError                 */
   INFLX_ERR_ARG = 6,     /* invalid argument (NULL, bad enum)      -> ValueError; the reference
                             panics on the analogous conditions (anguelova.rs:473,501)             */
-  INFLX_ERR_BASIS = 7    /* basis not orthonormal (BasisNorm/BasisOth) -> Exception (err.rs:36-37,72) */
+  INFLX_ERR_BASIS = 7,   /* basis not orthonormal (BasisNorm/BasisOth) -> Exception (err.rs:36-37,72) */
+  INFLX_ERR_GSL = 8      /* a special function was called outside its domain (see inflx_sf_policy): the reference's GSL error
+                            handler prints the reason and panics (err.rs:86-103) -> ArithmeticError       */
 } inflx_status;
+
+/* bits of a model's special-function status (csrc/inflx_sf.h) */
+typedef enum inflx_sf_bits {
+  INFLX_SF_EDOM = 1,      /* an argument outside the function's domain: GSL_EDOM (1) in the reference's GSL */
+  INFLX_SF_EDECLINED = 2  /* inside the domain, but the device function could not deliver 1e-13 and returned NaN
+                             rather than a plausible number (GSL's counterparts: GSL_ELOSS, GSL_EMAXITER, GSL_EUNIMPL) */
+} inflx_sf_bits;
+
+typedef enum inflx_sf_policy_t {
+  INFLX_SF_QUIET = 0, /* NaN at the point, nothing else */
+  INFLX_SF_FAIL = 1   /* the call that finds a bit set returns INFLX_ERR_GSL -- after its result is complete */
+} inflx_sf_policy_t;
 
 /* per-point operation selector; numbering shared with the kernels (csrc/inflx_kernel_abi.h) */
 typedef enum inflx_op {
@@ -291,8 +305,32 @@ int inflx_sweep_device_stats(inflx_model* model, const double* p, size_t P, size
                              const double* start_stop, size_t N0, size_t N1, size_t row_begin, size_t row_count,
                              void* stream, inflx_summary* summary);
 
-/* wait for everything enqueued on the model's own stream */
+/* wait for everything enqueued on the model's own stream (under INFLX_SF_FAIL this is where the asynchronous device-resident
+ * sweeps report a special-function error) */
 int inflx_synchronize(inflx_model* model);
+
+/*
+ * Special functions outside their domain.  The reference links GSL for sympy's Bessel and hypergeometric functions
+ * (python/inflatox/compiler.py:123-212) and, when the artefact says USE_GSL = 1, installs an error handler that prints the reason
+ * and panics (compiler.py:145-149 `err_setup`, src/dylib.rs:141-148, src/err.rs:86-103): a sweep that evaluates, say, K_nu at
+ * x <= 0 anywhere on its grid does not return.  The device counterparts (csrc/inflx_sf.h) return NaN for the point and set a bit in
+ * the code object's status word; what the host makes of it is the handle's policy:
+ *   INFLX_SF_FAIL  (default when USE_GSL = 1) -- every call that hands results to the host (the inflx_sweep_host* family, the named
+ *                  sweeps, inflx_sweep_on_trajectory, inflx_sweep_device_stats, the *_multi forms, and inflx_synchronize for
+ *                  the asynchronous device-resident sweeps) returns INFLX_ERR_GSL, with the reference handler's first line in
+ *                  inflx_last_error(), AFTER the result has been written: the caller's array is complete, NaN at the points;
+ *   INFLX_SF_QUIET (default otherwise)        -- NaN at the points, INFLX_OK.
+ * inflx_sf_status: OR of the bits (inflx_sf_bits) set since they were last cleared, after waiting for the handle's streams;
+ * `clear` != 0 resets them.  Reported conditions: the argument domains GSL documents (nu >= 0; Y, K, y_l for x > 0; J_nu, I_nu, j_l
+ * for x >= 0; 0F1 / 1F1 / 2F1 with the lower parameter a non-positive integer; 2F1 outside -1 <= x < 1; 2F0 for x > 0) and this
+ * implementation's own refusals.  A NaN argument is not an error (it propagates, as through GSL's comparisons).  NOT reported:
+ * overflow and underflow (+-inf / 0 here; GSL_EOVRFLW / GSL_EUNDRFLW reach the reference's handler too).  GSL itself is not part of the
+ * reference's sources or of this image: which arguments it rejects is taken from its manual, not from a run.
+ */
+int inflx_sf_status(inflx_model* model, unsigned* bits, int clear);
+int inflx_sf_policy(inflx_model* model, int policy);
+/* the artefact's USE_GSL global (0 / 1): Compiler(link_gsl=True), compiler.py:558, dylib.rs:135-141 */
+int inflx_uses_gsl(const inflx_model* model);
 
 /*
  * One call, several GPUs.  The reference's knob for "use the whole machine" is the `threads` argument of its sweeps:

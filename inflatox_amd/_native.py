@@ -17,7 +17,9 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 _REPO = os.path.dirname(_PKG)
 LIB_PATH = os.path.join(_PKG, "libinflx_hip.so")
 
-OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG, ERR_BASIS = range(8)
+OK, ERR_IO, ERR_SYMBOL, ERR_VERSION, ERR_SHAPE, ERR_DEVICE, ERR_ARG, ERR_BASIS, ERR_GSL = range(9)
+SF_EDOM, SF_EDECLINED = 1, 2  # inflx_sf_bits
+SF_QUIET, SF_FAIL = 0, 1  # inflx_sf_policy_t
 
 OP_COMPLETE, OP_CONSISTENCY, OP_RAPIDTURN, OP_EPSILON_V, OP_RAW = range(5)
 OP_HESSE = 6  # v00, v01, v10, v11: the projected Hesse matrix with the reference's own v01 (INFLX_SWEEP_HESSE)
@@ -78,6 +80,9 @@ SIGNATURES = {
         [C.c_void_p, _DP, _SIZE, _SIZE, C.c_void_p, _SIZE, _DP, _SIZE, _SIZE, _SIZE, _SIZE, C.c_void_p, C.c_void_p],
     ),
     "inflx_synchronize": (C.c_int, [C.c_void_p]),
+    "inflx_sf_status": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint), C.c_int]),
+    "inflx_sf_policy": (C.c_int, [C.c_void_p, C.c_int]),
+    "inflx_uses_gsl": (C.c_int, [C.c_void_p]),
     "inflx_sweep_plan": (C.c_int, [C.c_void_p, C.c_int, _SIZE, _SIZE, _SIZE, C.c_int, C.POINTER(C.c_uint32)]),
     "inflx_basis_on_points": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, _SIZE, _DP]),
     "inflx_ops_on_values": (C.c_int, [C.c_void_p, _DP, _SIZE, _DP, C.c_int]),
@@ -180,8 +185,16 @@ class InflatoxBasisError(Exception):
     """Counterpart of LibInflxRsErr::BasisNorm / BasisOth (err.rs:36-37), plain Exceptions in PyO3 too."""
 
 
+class InflatoxSpecialFunctionError(ArithmeticError):
+    """A special function of the model was called outside its domain somewhere in the call (``INFLX_ERR_GSL``).  The reference's
+    GSL error handler prints the reason and panics at that point (src/err.rs:86-103): the call does not return there either.  Here
+    the result was complete when the error was raised -- NaN at the offending points -- and ``sf_errors="nan"`` returns it."""
+
+
 def _raise(rc: int):
     msg = load_library().inflx_last_error().decode("utf-8", "replace")
+    if rc == ERR_GSL:
+        raise InflatoxSpecialFunctionError(msg)
     if rc == ERR_IO:
         raise IOError(msg)
     if rc in (ERR_SYMBOL, ERR_VERSION, ERR_DEVICE):
@@ -196,6 +209,13 @@ def _raise(rc: int):
 def _check(rc: int):
     if rc != OK:
         _raise(rc)
+
+
+def _sf_policy(mode: str) -> int:
+    try:
+        return {"raise": SF_FAIL, "nan": SF_QUIET}[mode]
+    except (KeyError, TypeError):
+        raise ValueError(f'sf_errors must be "raise" or "nan" (got {mode!r})') from None
 
 
 def _f64(a, name: str) -> np.ndarray:
@@ -272,6 +292,24 @@ class InflatoxDevLib:
     def _need(self, group: str) -> None:
         """The kernel group of the operation about to run (built and attached on first use; see ``_ensure_group``)."""
         _ensure_group(self._lib, [self._h], self._artefact, group)
+
+    # ---- special functions outside their domain (include/inflx_hip.h: inflx_sf_policy) -----------
+    @property
+    def uses_gsl(self) -> bool:
+        """The artefact's ``USE_GSL`` global: ``Compiler(link_gsl=True)``."""
+        return bool(self._lib.inflx_uses_gsl(self._h))
+
+    def sf_status(self, clear: bool = True) -> int:
+        """Bits (``SF_EDOM``, ``SF_EDECLINED``) the model's special functions have set since they were last cleared; waits for
+        the handle's streams."""
+        bits = C.c_uint(0)
+        _check(self._lib.inflx_sf_status(self._h, C.byref(bits), int(bool(clear))))
+        return int(bits.value)
+
+    def set_sf_errors(self, mode: str) -> None:
+        """``"raise"``: a call that evaluated a special function outside its domain raises :class:`InflatoxSpecialFunctionError`
+        (the default for ``link_gsl=True`` artefacts, where the reference panics); ``"nan"``: NaN at the point, nothing else."""
+        _check(self._lib.inflx_sf_policy(self._h, _sf_policy(mode)))
 
     @property
     def groups(self) -> int:
@@ -543,6 +581,12 @@ class InflatoxMultiLib:
     def _need(self, group: str) -> None:
         handles = [self._lib.inflx_multi_handle(self._h, k) for k in range(self.n_devices)]
         _ensure_group(self._lib, handles, self._artefact, group)
+
+    def set_sf_errors(self, mode: str) -> None:
+        """:meth:`InflatoxDevLib.set_sf_errors` for every device of the handle."""
+        policy = _sf_policy(mode)
+        for k in range(self.n_devices):
+            _check(self._lib.inflx_sf_policy(self._lib.inflx_multi_handle(self._h, k), policy))
 
     def complete_analysis(self, p, out, start_stop, progress=False, threads=0):
         """``libinflx_rs.complete_analysis(lib, p, out, start_stop, progress, threads)`` (anguelova.rs:458) on the handle's

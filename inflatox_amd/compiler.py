@@ -419,8 +419,11 @@ class Compiler:
 
     ``link_gsl``: the reference links GSL for sympy's Bessel and hypergeometric functions
     (compiler.py:123-212).  Here nothing is linked: the Bessel functions (integer and real order; spherical ones of integer
-    order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h) and
-    print with or without the flag, which only sets the artefact's ``USE_GSL`` global.
+    order) and 0F1, 1F1, 2F1, 2F0 are device functions of this package (csrc/inflx_sf.h).  As in the reference they print only with
+    the flag (``GSLInflatoxPrinter``; without it sympy's printer refuses them), which also sets the artefact's ``USE_GSL`` global:
+    where the reference then installs a GSL error handler that panics (compiler.py:145-149, src/dylib.rs:141-148), a call that
+    evaluated one of these functions outside its domain fails with ``InflatoxSpecialFunctionError`` once its result is complete
+    (``GeneralisedAL(..., sf_errors="nan")`` returns the arrays with NaN at those points instead; include/inflx_hip.h ``inflx_sf_policy``).
     """
 
     #: `hoist_reciprocals=None` turns the quick point stage (hoisted and shared reciprocals) on when it removes at least

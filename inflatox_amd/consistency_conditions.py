@@ -29,8 +29,14 @@ def _start_stop(x0_start, x0_stop, x1_start, x1_stop) -> np.ndarray:
 class InflationCondition:
     """Base class: owns the opened model artefact (reference consistency_conditions.py:31-50)."""
 
-    def __init__(self, compiled_artifact: CompilationArtifact, validate_basis: bool = True, *, device: int = 0, devices=None, tuned: bool = False):
-        """``tuned`` (extension, keyword-only, default off): profile-guided build.  The FIRST grid sweep of this object hands
+    def __init__(self, compiled_artifact: CompilationArtifact, validate_basis: bool = True, *, device: int = 0, devices=None, tuned: bool = False, sf_errors: str | None = None):
+        """``sf_errors`` (extension, keyword-only): what a call does when the model evaluated a Bessel / hypergeometric function
+        outside its domain somewhere on the grid.  ``"raise"``: :class:`inflatox_amd._native.InflatoxSpecialFunctionError` once the
+        sweep has finished -- the reference's GSL error handler panics there (src/err.rs:86-103); ``"nan"``: the arrays are
+        returned with NaN at those points.  Default (``None``): ``"raise"`` for ``Compiler(link_gsl=True)`` artefacts -- the only
+        ones the reference can build such a model from --, ``"nan"`` otherwise.
+
+        ``tuned`` (extension, keyword-only, default off): profile-guided build.  The FIRST grid sweep of this object hands
         its own parameter values and field range to ``artifact.profile_guided`` -- the call supplies everything the measurement
         needs (reference consistency_conditions.py:226-308: args, the four range values) -- and this and every later call
         run on that build (EGNO 4096^2: 0.40 -> 0.32 ms of device time).  Results then agree with the reference within the
@@ -51,9 +57,17 @@ class InflationCondition:
             self.multi = InflatoxMultiLib(compiled_artifact.shared_object_path, devices)
             device = self.multi.devices[0]
         self.dylib: InflatoxDevLib = open_inflx_dylib(compiled_artifact.shared_object_path, validate_basis, device=device)
+        self._sf_errors = sf_errors
+        self._apply_sf_errors(self.dylib, self.multi)
         self._tune_pending = bool(tuned)
         self._tune_lock = threading.Lock()  # two first sweeps that arrive together measure and swap handles once
         self.tuned_on = None  # (args, extent) the profile-guided build was measured on
+
+    def _apply_sf_errors(self, dylib, multi) -> None:
+        if self._sf_errors is not None:
+            dylib.set_sf_errors(self._sf_errors)
+            if multi is not None:
+                multi.set_sf_errors(self._sf_errors)
 
     def retune(self, args, extent) -> None:
         """Extension: (re)build the profile-guided code object for the parameter values ``args`` and the field range
@@ -66,6 +80,7 @@ class InflationCondition:
         device = self.dylib.device
         new_multi = InflatoxMultiLib(art.shared_object_path, self._devices) if self._devices is not None else None
         new_dylib = open_inflx_dylib(art.shared_object_path, False, device=device)  # the basis was validated on the default build
+        self._apply_sf_errors(new_dylib, new_multi)
         old_dylib, old_multi = self.dylib, self.multi
         self.dylib, self.multi, self.artifact = new_dylib, new_multi, art
         self._tune_pending = False
@@ -142,9 +157,9 @@ class GeneralisedAL(InflationCondition):
     """Generalised Anguelova-Lazaroiu consistency condition and the quantities derived from it
     (reference consistency_conditions.py:199-715)."""
 
-    def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0, devices=None, tuned: bool = False):
+    def __init__(self, compiled_artifact: CompilationArtifact, *, device: int = 0, devices=None, tuned: bool = False, sf_errors: str | None = None):
         # like the reference (consistency_conditions.py:222-224 -> :38), the constructor validates the basis
-        super().__init__(compiled_artifact, device=device, devices=devices, tuned=tuned)
+        super().__init__(compiled_artifact, device=device, devices=devices, tuned=tuned, sf_errors=sf_errors)
 
     # ---- the hot path ------------------------------------------------------------------------
     def complete_analysis(

@@ -348,6 +348,11 @@ struct inflx_model {
   uint32_t groups = 0;
   std::vector<hipModule_t> attached;
   std::string tag;  // MODEL_TAG of the core object: what an attached group must carry too
+  // special-function status (csrc/inflx_sf.h): one INFLX_SF_STATUS word per loaded code object of a model that calls inflx_sf_*;
+  // empty for every other model.  `sf_policy`: what a host-result call does when a word is set (inflx_sf_policy)
+  std::vector<hipDeviceptr_t> sf_words;
+  int sf_policy = INFLX_SF_QUIET;
+  char use_gsl = 0;  // the artefact's USE_GSL global (Compiler(link_gsl=True), python/inflatox/compiler.py:558)
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
   std::string name, path;
@@ -450,6 +455,58 @@ int release_params_after(inflx_model* m, hipStream_t reader, int rc) {
   return rc;
 }
 
+// ---- special-function status ------------------------------------------------------------------------------------------------
+// A model that calls the device counterparts of the reference's gsl_sf_* functions (csrc/inflx_sf.h) carries the word
+// INFLX_SF_STATUS in each of its code objects; a function that is called outside its domain returns NaN for the point and sets a
+// bit there.  The reference's GSL error handler prints the reason and panics (src/err.rs:86-103, installed by src/dylib.rs:141-148
+// when USE_GSL = 1): the call does not return.  Here the host reads the words after the sweep.
+void note_sf_word(inflx_model* m, hipModule_t module) {
+  hipDeviceptr_t dptr = nullptr;
+  size_t size = 0;
+  if (hipModuleGetGlobal(&dptr, &size, module, "INFLX_SF_STATUS") == hipSuccess && size == sizeof(unsigned))
+    m->sf_words.push_back(dptr);
+  else
+    (void)hipGetLastError();  // a model without special functions has no such word
+}
+
+// OR of the status words of every code object of the handle; everything the handle has enqueued is waited for first
+int sf_collect(inflx_model* m, bool clear, unsigned* bits) {
+  *bits = 0;
+  if (m->sf_words.empty()) return INFLX_OK;
+  HIP_TRY(hipSetDevice(m->device));
+  HIP_TRY(hipStreamSynchronize(m->side));
+  HIP_TRY(hipStreamSynchronize(m->stream));
+  for (hipDeviceptr_t w : m->sf_words) {
+    unsigned v = 0;
+    HIP_TRY(hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost));
+    *bits |= v;
+    if (v && clear) {
+      const unsigned zero = 0;
+      HIP_TRY(hipMemcpy(w, &zero, sizeof zero, hipMemcpyHostToDevice));
+    }
+  }
+  return INFLX_OK;
+}
+
+int sf_error(const inflx_model* m, unsigned bits) {
+  // (the first words are the reference handler's, src/err.rs:98 -- spelling included; GSL_EDOM = 1, GSL_ELOSS = 17)
+  const bool dom = (bits & INFLX_SF_EDOM) != 0;
+  return fail(INFLX_ERR_GSL, "a GSL exception ocurred (ERRCODE %s): model \"%s\" called a special function %s at one or more points of this call. "
+              "Those points hold NaN and the result is complete otherwise; the reference's GSL error handler panics here instead of returning. "
+              "inflx_sf_policy(handle, INFLX_SF_QUIET) / GeneralisedAL(..., sf_errors=\"nan\") returns the result with its NaNs.",
+              dom ? "0X1" : "0X11", m->name.c_str(),
+              dom ? "outside its domain (input domain error)" : "where this implementation could not deliver 1e-13 and declined (loss of accuracy)");
+}
+
+// what a host-result call returns after its result is complete
+int sf_verdict(inflx_model* m) {
+  if (m->sf_words.empty() || m->sf_policy != INFLX_SF_FAIL) return INFLX_OK;
+  unsigned bits = 0;
+  const int rc = sf_collect(m, true, &bits);
+  if (rc) return rc;
+  return bits ? sf_error(m, bits) : INFLX_OK;
+}
+
 // ---- kernel groups ----------------------------------------------------------------------------------------------------------
 const char* const kGroupNames[9] = {"core", "stats", "values", "consistency", "rapidturn", "epsilon_v", "raw", "qdif", "hesse"};
 uint32_t group_of_op(int op) { return INFLX_GROUP_OF_OP(op); }
@@ -524,6 +581,7 @@ int attach_object(inflx_model* m, const char* path) {
   if ((rc = resolve_group_kernels(m, module, fresh, path))) return bail(rc);
   m->attached.push_back(module);
   m->groups |= fresh;
+  note_sf_word(m, module);
   return INFLX_OK;
 }
 
@@ -1135,6 +1193,10 @@ int inflx_open(const char* artefact_path, int device, inflx_model** out) {
          INFLX_KERNEL_ABI);
     return bail(INFLX_ERR_VERSION);
   }
+  if ((rc = read_global(m, "USE_GSL", &m->use_gsl, sizeof m->use_gsl, true))) return bail(rc);
+  note_sf_word(m, m->module);
+  // with GSL linked the reference installs a handler that panics on the first GSL error (src/dylib.rs:141-148): a call fails
+  m->sf_policy = m->use_gsl ? INFLX_SF_FAIL : INFLX_SF_QUIET;
   char tag[128] = {0};
   if ((rc = read_global(m, "INFLX_GROUPS", &m->groups, sizeof m->groups, true))) return bail(rc);
   if ((rc = read_global(m, "MODEL_TAG", tag, sizeof tag - 1, false))) return bail(rc);
@@ -1332,7 +1394,7 @@ int inflx_sweep_device_stats(inflx_model* m, const double* p, size_t P, size_t n
   HIP_TRY(hipMemcpyAsync(summary, m->d_stats, sizeof *summary, hipMemcpyDeviceToHost, eval));
   HIP_TRY(hipStreamSynchronize(eval));
   if (eval != s) HIP_TRY(hipStreamSynchronize(s));
-  return INFLX_OK;
+  return sf_verdict(m);
 }
 
 int inflx_synchronize(inflx_model* m) {
@@ -1341,8 +1403,24 @@ int inflx_synchronize(inflx_model* m) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->side));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  return sf_verdict(m);  // the device-resident sweeps are asynchronous: this is where they report
+}
+
+int inflx_sf_status(inflx_model* m, unsigned* bits, int clear) {
+  if (!m || !bits) return fail(INFLX_ERR_ARG, "model handle / status pointer is NULL");
+  INFLX_SERIALISE(m);
+  return sf_collect(m, clear != 0, bits);
+}
+
+int inflx_sf_policy(inflx_model* m, int policy) {
+  if (!m) return fail(INFLX_ERR_ARG, "model handle is NULL");
+  if (policy != INFLX_SF_QUIET && policy != INFLX_SF_FAIL) return fail(INFLX_ERR_ARG, "unknown special-function policy %d", policy);
+  INFLX_SERIALISE(m);
+  m->sf_policy = policy;
   return INFLX_OK;
 }
+
+int inflx_uses_gsl(const inflx_model* m) { return m ? (int)m->use_gsl : 0; }
 
 int inflx_sweep_device(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,
                        const double* ss, size_t N0, size_t N1, size_t row_begin, size_t row_count, int layout, void* stream) {
@@ -1491,7 +1569,10 @@ int inflx_basis_on_points(inflx_model* m, const double* p, size_t n_p, const dou
   HIP_TRY(hipModuleLaunchKernel(m->basis_points, (unsigned)gx, 1, 1, m->info.tile_cols, 1, 1, 0, m->stream, params, nullptr));
   HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  return INFLX_OK;
+  // The basis checks judge the values themselves (a NaN fails `is_normal`, src/lib.rs:176-205): what the special functions noted at
+  // these probe points is dropped here, so that it is not reported by the next sweep.
+  unsigned dropped = 0;
+  return sf_collect(m, true, &dropped);
 }
 
 int inflx_ops_on_values(inflx_model* m, const double* values, size_t n, double* out, int ieee_only) {
@@ -1739,7 +1820,7 @@ void parallel_blocks(size_t n, size_t bytes_per_item, F fill) {
   for (auto& th : pool) th.join();
 }
 
-int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
+int sweep_host_body(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
                     size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy, HostDest dest, Progress* progress);
 
 // The broadcast form of a host-result sweep (see above); `axis` = 1: nothing depends on x[1], 0: nothing depends on x[0].
@@ -1755,7 +1836,7 @@ int sweep_host_broadcast(inflx_model* m, int op, int axis, const double* p, size
   if (axis == 1) {
     // one column of the grid: (P, row_count, 1, K) resp. (P, K, row_count, 1)
     std::vector<double> line(P * row_count * K);
-    if ((rc = sweep_host_impl(m, op, p, P, n_p, line.data(), ss, N0, 1, row_begin, row_count, layout, 0.0, HostDest(), nullptr))) return rc;
+    if ((rc = sweep_host_body(m, op, p, P, n_p, line.data(), ss, N0, 1, row_begin, row_count, layout, 0.0, HostDest(), nullptr))) return rc;
     const char* src = reinterpret_cast<const char*>(line.data());
     parallel_blocks(blocks * row_count, dst_row_bytes, [&](size_t first, size_t last) {
       for (size_t q = first; q < last; ++q) {
@@ -1769,7 +1850,7 @@ int sweep_host_broadcast(inflx_model* m, int op, int axis, const double* p, size
   }
   // one row of the grid: (P, 1, N1, K) resp. (P, K, 1, N1)
   std::vector<double> image(P * N1 * K);
-  if ((rc = sweep_host_impl(m, op, p, P, n_p, image.data(), ss, N0, N1, row_begin, 1, layout, 0.0, HostDest(), nullptr))) return rc;
+  if ((rc = sweep_host_body(m, op, p, P, n_p, image.data(), ss, N0, N1, row_begin, 1, layout, 0.0, HostDest(), nullptr))) return rc;
   const char* src = reinterpret_cast<const char*>(image.data());
   parallel_blocks(blocks * row_count, dst_row_bytes, [&](size_t first, size_t last) {
     for (size_t q = first; q < last; ++q) {
@@ -1783,7 +1864,7 @@ int sweep_host_broadcast(inflx_model* m, int op, int axis, const double* p, size
 }
 
 // host-result sweep for every operation; the slab holds kOpBytes[op] bytes per grid point
-int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
+int sweep_host_body(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
                     size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy, HostDest dest, Progress* progress) {
   INFLX_SERIALISE(m);
   char* const out = static_cast<char*>(out_v);
@@ -2013,6 +2094,14 @@ int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_
   if (progress)
     for (; counted < pieces.size(); ++counted) progress->done += pieces[counted].nrows * piece_row_bytes;
   return INFLX_OK;
+}
+
+// the sweep, then what the special functions had to say about it (the result is complete in the caller's memory either way)
+int sweep_host_impl(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* out_v, const double* ss, size_t N0,
+                    size_t N1, size_t row_begin, size_t row_count, int layout, double accuracy, HostDest dest, Progress* progress) {
+  INFLX_SERIALISE(m);
+  const int rc = sweep_host_body(m, op, p, P, n_p, out_v, ss, N0, N1, row_begin, row_count, layout, accuracy, dest, progress);
+  return rc ? rc : sf_verdict(m);
 }
 
 // ---- progress lines of long host-result calls --------------------------------------------------------------------------
@@ -2361,7 +2450,7 @@ int inflx_sweep_on_trajectory(inflx_model* m, int op, const double* p, size_t n_
   if (out_bytes >= (size_t(4) << 20)) prefault_range(reinterpret_cast<char*>(out), out_bytes);
   HIP_TRY(hipMemcpyAsync(out, m->d_chunk[0], out_bytes, hipMemcpyDeviceToHost, m->stream));
   HIP_TRY(hipStreamSynchronize(m->stream));
-  return INFLX_OK;
+  return sf_verdict(m);
 }
 
 

@@ -35,5 +35,11 @@ F2R(Jnu) F2R(Ynu) F2R(Inu) F2R(Knu)
 void sf_1F1(double a, double b, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_1F1(a, b, x[i]); }
 void sf_2F1(double a, double b, double c, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_2F1(a, b, c, x[i]); }
 void sf_2F0(double a, double b, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_2F0(a, b, x[i]); }
+// the status word the functions above leave their domain / declined notes in (csrc/inflx_sf.h); reading clears it
+unsigned sf_status_take() {
+  const unsigned v = inflx_sf_status_host;
+  inflx_sf_status_host = 0u;
+  return v;
+}
 void sf_0F1(double c, const double* x, int n, double* out) { for (int i = 0; i < n; ++i) out[i] = inflx_sf_hyperg_0F1(c, x[i]); }
 }

@@ -102,6 +102,53 @@ def test_symmetries_domains_and_limits(sf):
     assert abs(call(sf, "I", 0, np.array([712.0]))[0] / 2.4684110577627523e307 - 1) < 1e-13  # no premature overflow
 
 
+def test_status_word_records_domain_errors_and_refusals(sf):
+    """What the reference's GSL error handler would be called for (python/inflatox/compiler.py:145-149, src/err.rs:86-103) leaves a
+    bit in the status word (csrc/inflx_sf.h: INFLX_SF_EDOM = 1, INFLX_SF_EDECLINED = 2) besides the NaN; arguments inside the domain
+    and NaN arguments leave none."""
+    sf.sf_status_take.restype = C.c_uint
+    sf.sf_status_take()
+    inside = np.array([0.25, 1.0, 7.5, 40.0])
+    for kind in "JYIKjy":
+        for order in (0, 1, 2, 5):
+            assert np.isfinite(call(sf, kind, order, inside)).all()
+    for kind in "JYIK":
+        assert np.isfinite(_real(sf, kind, 0.5, inside)).all() and np.isfinite(_real(sf, kind, 3.25, inside)).all()
+    assert np.isfinite(_hyp(sf, "0F1", (1.5,), inside)).all() and np.isfinite(_hyp(sf, "1F1", (0.5, 1.5), inside)).all()
+    assert np.isfinite(_hyp(sf, "2F1", (0.5, 1.0, 1.5), np.array([-0.9, 0.0, 0.5, 0.95]))).all()
+    assert np.isfinite(_hyp(sf, "2F0", (0.5, 1.0), np.array([-3.0, -0.01, 0.0]))).all()
+    assert sf.sf_status_take() == 0
+    nan = np.array([np.nan])
+    for kind in "YKyj":
+        assert np.isnan(call(sf, kind, 1, nan)).all() and np.isnan(call(sf, kind, 4, nan)).all()
+    for kind in "JYIK":
+        assert np.isnan(_real(sf, kind, 0.5, nan)).all() and np.isnan(_real(sf, kind, np.nan, inside)).all()
+    assert np.isnan(_hyp(sf, "2F1", (0.5, 1.0, 1.5), nan)).all() and np.isnan(_hyp(sf, "2F0", (0.5, 1.0), nan)).all()
+    assert sf.sf_status_take() == 0, "a NaN argument is not a domain error"
+    cases = [(lambda k=kind, n=order: call(sf, k, n, np.array([-1.0]))) for kind in "YKyj" for order in (0, 1, 2, 4)]
+    cases += [(lambda k=kind: call(sf, k, 3, np.array([0.0]))) for kind in "YKy"]
+    cases += [(lambda k=kind: _real(sf, k, -0.5, np.array([1.0]))) for kind in "JYIK"]  # negative order
+    cases += [(lambda k=kind: _real(sf, k, 0.5, np.array([-1.0]))) for kind in "JYIK"]
+    cases += [(lambda k=kind: _real(sf, k, 0.5, np.array([0.0]))) for kind in "YK"]
+    cases += [lambda: _hyp(sf, "0F1", (-2.0,), np.array([1.0])), lambda: _hyp(sf, "1F1", (0.5, -1.0), np.array([1.0])),
+              lambda: _hyp(sf, "2F1", (0.5, 1.0, -3.0), np.array([0.5])), lambda: _hyp(sf, "2F1", (0.5, 1.0, 1.5), np.array([1.0])),
+              lambda: _hyp(sf, "2F1", (0.5, 1.0, 1.5), np.array([-1.5])), lambda: _hyp(sf, "2F0", (0.5, 1.0), np.array([0.5]))]
+    for k, case in enumerate(cases):
+        assert np.isnan(case()).all(), k
+        assert sf.sf_status_take() == 1, k  # INFLX_SF_EDOM
+        assert sf.sf_status_take() == 0, k  # reading cleared it
+    # refusals: inside the domain, no answer to 1e-13
+    assert np.isnan(_real(sf, "J", 2e7, np.array([1.0]))).all() and sf.sf_status_take() == 2
+    assert np.isnan(_hyp(sf, "2F0", (0.1, 0.2), np.array([-5.0]))).all() and sf.sf_status_take() == 2
+
+
+def _real(lib, kind, order, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    getattr(lib, f"sf_{kind}nu")(C.c_double(order), x.ctypes.data_as(DP), x.size, out.ctypes.data_as(DP))
+    return out
+
+
 def test_gsl_printer_strings_match_the_reference():
     """The strings of the reference's tests/test_compiler.py:56-84."""
     x, y, a, b, xdot, ydot = sympy.symbols("x y a b \\dot{{x}} \\dot{{y}}")

@@ -26,6 +26,7 @@ def test_every_device_bessel_function_against_mpmath(gpu_lib):
 
     model, comp, art = _build(example_models.bessel_probe, "bessel_probe", assertions=False, simplify=False)
     cond = InflationCondition(art, validate_basis=False)
+    cond.dylib.set_sf_errors("nan")  # a probe of V alone: its derivatives' orders (nu - 1, j_(-1), ...) may leave GSL's domain, which fails the call otherwise
     rng = np.random.default_rng(5)
     xs = np.concatenate([rng.uniform(0.05, 4, 12), rng.uniform(4, 40, 20), [2.0, 3.0, 4.0, 8.0]])
     pts = np.stack([xs, np.zeros_like(xs)], axis=1)
@@ -90,9 +91,14 @@ def test_integer_bessel_and_0F1_model_on_the_gpu(gpu_lib):
     raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), n0, n1).reshape(-1, 5)
     scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
     assert np.isfinite(want).all() and (np.abs(raw - want) / scale).max() < 1e-10
-    # c = 0 is a pole of 0F1: NaN, as GSL's domain error would have it
+    # c = 0 is a pole of 0F1 -- GSL's domain error, which the reference's handler turns into a panic (src/err.rs:86-103): the call
+    # fails like the reference's (link_gsl=True: INFLX_SF_FAIL), and returns NaN there when told to
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError, match=r"a GSL exception ocurred \(ERRCODE 0X1\)"):
+        al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 0.0]), np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), 4, 4)
+    al.dylib.set_sf_errors("nan")
     bad = al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 0.0]), np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), 4, 4)
     assert np.isnan(bad[..., 0]).all()
+    assert al.dylib.sf_status() == gpu_lib.SF_EDOM and al.dylib.sf_status() == 0
 
 
 def test_real_order_bessel_model_on_the_gpu(gpu_lib):
@@ -114,7 +120,11 @@ def test_real_order_bessel_model_on_the_gpu(gpu_lib):
         raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, ss, n0, n1).reshape(-1, 5)
         scale = np.maximum(np.abs(want), np.abs(want).max(axis=0, keepdims=True) * 1e-3)
         assert np.isfinite(want).all() and (np.abs(raw - want) / scale).max() < 1e-10, nu
-    # an order below GSL's domain (nu - 2 < 0 in the second derivatives): NaN, as GSL's domain error would have it
+    # an order below GSL's domain (nu - 2 < 0 in the second derivatives): GSL's domain error -- the call fails as the reference's
+    # does, and with sf_errors="nan" the values are NaN where the function was outside its domain and only there
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+        al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 1.5]), ss, 4, 4)
+    al.dylib.set_sf_errors("nan")
     bad = al.dylib.sweep_host(gpu_lib.OP_RAW, np.array([1.2, 1.5]), ss, 4, 4)
     assert np.isnan(bad[..., 1]).all() and np.isfinite(bad[..., 0]).all()
 
@@ -136,6 +146,7 @@ def test_real_order_bessel_device_functions_against_mpmath(kind, gpu_lib):
     model = InflationModelBuilder.new([phi, theta], [[1, 0], [0, 1]], fn_sym(nu, phi), model_name=f"probe_{kind}nu", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
     art = Compiler(model, silent=True, link_gsl=True).compile()
     cond = InflationCondition(art, validate_basis=False)
+    cond.dylib.set_sf_errors("nan")  # a probe of V alone: its derivatives' orders (nu - 1, j_(-1), ...) may leave GSL's domain, which fails the call otherwise
     rng = np.random.default_rng(4)
     xs = np.concatenate([10.0 ** rng.uniform(-9, 0, 6), rng.uniform(0, 4, 8), rng.uniform(4, 60, 12), rng.uniform(60, 250 if kind in "IK" else 400, 4)])
     pts = np.stack([xs, np.zeros_like(xs)], axis=1)
@@ -205,6 +216,7 @@ def test_hypergeometric_device_functions_against_mpmath(family, gpu_lib):
     model = InflationModelBuilder.new([phi, theta], [[1, 0], [0, 1]], expr, model_name=f"probe_{family}", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
     art = Compiler(model, silent=True, link_gsl=True).compile()
     cond = InflationCondition(art, validate_basis=False)
+    cond.dylib.set_sf_errors("nan")  # a probe of V alone: its derivatives' orders (nu - 1, j_(-1), ...) may leave GSL's domain, which fails the call otherwise
     slot = [int(art.symbol_dictionary[n][5:-1]) for n in names]
     rng = np.random.default_rng(8)
     cases = {
@@ -236,3 +248,73 @@ def test_hypergeometric_device_functions_against_mpmath(family, gpu_lib):
                 worst = max(worst, err)
                 assert err < 2e-12, (family, params, xi, g, float(want), err)
     print(f"{family}: worst error on the device {worst:.2e}")
+
+
+def test_special_function_domain_errors_fail_the_call_like_the_reference(gpu_lib):
+    """The reference links GSL with an error handler that prints the reason and panics (python/inflatox/compiler.py:145-149,
+    src/dylib.rs:141-148, src/err.rs:86-103): a sweep whose grid leaves a function's domain does not return.  Here the sweep finishes,
+    the points hold NaN, and the call raises InflatoxSpecialFunctionError (INFLX_ERR_GSL) -- by default for a link_gsl=True artefact,
+    never for sf_errors="nan" -- on every path that hands results to the host: the grid sweeps (tile and row-broadcast kernels), the
+    single-quantity sweeps (kernel groups attached later carry a status word of their own), the trajectory variants, the summary
+    sweep, and inflx_synchronize for the asynchronous device-resident sweep.  A grid inside the domain never raises, before or
+    after one that did."""
+    import sympy
+    import torch
+    from inflatox_amd import Compiler, InflationModelBuilder
+    from inflatox_amd.consistency_conditions import GeneralisedAL, InflationCondition
+
+    def GeneralisedAL_(art, **kw):  # (without the constructor's basis check at random points: some of those lie outside K_0's domain)
+        al = GeneralisedAL.__new__(GeneralisedAL)
+        InflationCondition.__init__(al, art, validate_basis=False, **kw)
+        return al
+
+    phi, theta, m = sympy.symbols("phi theta m")
+    # K_0 needs phi > 0; depends on both fields -> tile kernels
+    potential = m**2 * (3 + sympy.besselk(0, phi) + sympy.Rational(1, 10) * sympy.cos(theta) * phi)
+    model = InflationModelBuilder.new([phi, theta], [[1, 0], [0, phi**2 + 1]], potential, model_name="k0_domain", init_sympy_printing=False, silent=True, assertions=False, simplify=False).build()
+    art = Compiler(model, silent=True, link_gsl=True).compile()
+    args = np.array([1.1])
+    inside, outside = (0.5, 6.0, 0.1, 3.0), (-2.0, 6.0, 0.1, 3.0)  # a quarter of the second grid has phi <= 0
+    n0, n1 = 64, 48
+
+    al = GeneralisedAL_(art)
+    assert al.dylib.uses_gsl
+    good = al.complete_analysis(args, *inside, n0, n1, progress=False)
+    assert all(np.isfinite(a).any() for a in good[1:3])
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError, match="k0_domain"):
+        al.complete_analysis(args, *outside, n0, n1, progress=False)
+    again = al.complete_analysis(args, *inside, n0, n1, progress=False)  # the status was cleared by the call that reported it
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(good, again))
+    for name in ("consistency", "epsilon_v", "consistency_rapidturn"):  # groups built and attached on first use
+        getattr(al, name)(args, *inside, n0, n1, progress=False)
+        with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+            getattr(al, name)(args, *outside, n0, n1, progress=False)
+    pts_in = np.stack([np.linspace(0.5, 5.0, 40), np.full(40, 0.3)], axis=1)
+    pts_out = pts_in.copy()
+    pts_out[7, 0] = -0.25
+    al.complete_analysis_ot(args, pts_in, progress=False)
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+        al.complete_analysis_ot(args, pts_out, progress=False)
+    al.complete_analysis_summary(args, *inside, n0, n1)
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+        al.complete_analysis_summary(args, *outside, n0, n1)
+    # device-resident: asynchronous, reports at inflx_synchronize
+    ss = np.array([[outside[0], outside[1]], [outside[2], outside[3]]])
+    out = torch.empty(n0 * n1 * 6, dtype=torch.float64, device="cuda:0")
+    al.dylib.sweep_device(gpu_lib.OP_COMPLETE, args, out.data_ptr(), out.numel() * 8, ss, n0, n1, stream=torch.cuda.current_stream().cuda_stream)
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+        al.dylib.synchronize()
+    al.dylib.synchronize()
+
+    quiet = GeneralisedAL_(art, sf_errors="nan")
+    res = quiet.complete_analysis(args, *outside, n0, n1, progress=False)
+    x0 = outside[0] + np.arange(n0) * ((outside[1] - outside[0]) / n0)
+    for a in res:
+        assert np.isnan(a[x0 <= 0.0]).all()
+    assert np.isfinite(res[1][x0 > 0.0]).all()
+    # ... and where the function is inside its domain the values are those of the raising object's device-resident sweep, bit for bit
+    dev = out.cpu().numpy().reshape(n0, n1, 6)
+    assert all(np.array_equal(dev[..., k], res[k], equal_nan=True) for k in range(6))
+    assert quiet.dylib.sf_status() == gpu_lib.SF_EDOM
+    with pytest.raises(ValueError):
+        GeneralisedAL_(art, sf_errors="abort")
