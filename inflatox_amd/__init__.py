@@ -15,8 +15,24 @@ __all__ = [
     "InflationModelBuilder",
     "SymbolicCalculation",
     "consistency_conditions",
+    "log_info",
+    "log_warn",
     "__version__",
 ]
+
+
+def log_info(msg: str) -> None:
+    """``libinflx_rs.log_info`` (src/lib.rs:53-56,94-97): the message under the reference's badge line, on stderr."""
+    import sys
+
+    print(f"[Inflatox Info]\n{msg}", file=sys.stderr, flush=True)
+
+
+def log_warn(msg: str) -> None:
+    """``libinflx_rs.log_warn`` (src/lib.rs:58-61,99-102)."""
+    import sys
+
+    print(f"[Inflatox Warning]\n{msg}", file=sys.stderr, flush=True)
 
 
 def __getattr__(name):

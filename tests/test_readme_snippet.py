@@ -100,3 +100,19 @@ def test_readme_snippet_runs_end_to_end_on_the_gpu():
     assert np.array_equal(six[~fin & ~np.isnan(want)], want[~fin & ~np.isnan(want)])
     rel = np.abs(six[fin] - want[fin]) / np.maximum(np.abs(want[fin]), 1e-300)
     assert rel.max() <= 1e-10  # north_star's bar, no allowance
+
+
+def test_package_exports_the_reference_names(capsys):
+    """python/inflatox/__init__.py:20-40: everything the reference's package exports on the sweep path exists here under the
+    same name (`background`, the serial ODE solver, is out of scope); log_info / log_warn write the reference's badge lines
+    (src/lib.rs:53-61,94-102) to stderr."""
+    import inflatox_amd
+
+    for name in ("CompilationArtifact", "Compiler", "InflationModel", "InflationModelBuilder", "consistency_conditions", "log_info", "log_warn", "__version__"):
+        assert name in inflatox_amd.__all__, name
+    for name in ("CompilationArtifact", "Compiler", "InflationModel", "InflationModelBuilder", "log_info", "log_warn", "__version__"):
+        assert getattr(inflatox_amd, name) is not None
+    inflatox_amd.log_info("sweep done")
+    inflatox_amd.log_warn("outside the domain?")
+    err = capsys.readouterr().err
+    assert err == "[Inflatox Info]\nsweep done\n[Inflatox Warning]\noutside the domain?\n"
