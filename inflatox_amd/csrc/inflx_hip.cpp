@@ -352,6 +352,10 @@ struct inflx_model {
   // empty for every other model.  `sf_policy`: what a host-result call does when a word is set (inflx_sf_policy)
   std::vector<hipDeviceptr_t> sf_words;
   int sf_policy = INFLX_SF_QUIET;
+  // a device-resident sweep runs on the CALLER's stream, which the handle neither owns nor may assume alive later: an event of the
+  // handle's own is recorded behind the sweep, and reading the status waits for it
+  hipEvent_t sf_done = nullptr;
+  bool sf_pending = false;
   char use_gsl = 0;  // the artefact's USE_GSL global (Compiler(link_gsl=True), python/inflatox/compiler.py:558)
   uint16_t version[3] = {};
   uint32_t dim = 0, n_par = 0;
@@ -476,6 +480,10 @@ int sf_collect(inflx_model* m, bool clear, unsigned* bits) {
   HIP_TRY(hipSetDevice(m->device));
   HIP_TRY(hipStreamSynchronize(m->side));
   HIP_TRY(hipStreamSynchronize(m->stream));
+  if (m->sf_pending) {
+    HIP_TRY(hipEventSynchronize(m->sf_done));
+    m->sf_pending = false;
+  }
   for (hipDeviceptr_t w : m->sf_words) {
     unsigned v = 0;
     HIP_TRY(hipMemcpy(&v, w, sizeof v, hipMemcpyDeviceToHost));
@@ -1273,6 +1281,7 @@ void inflx_close(inflx_model* m) {
   }
   if (m->t0) (void)hipEventDestroy(m->t0);
   if (m->t1) (void)hipEventDestroy(m->t1);
+  if (m->sf_done) (void)hipEventDestroy(m->sf_done);
   for (auto& slot : m->pslot) {
     if (slot.dev) (void)hipFree(slot.dev);
     if (slot.host) (void)hipHostFree(slot.host);
@@ -1448,7 +1457,13 @@ int inflx_sweep_device_ex(inflx_model* m, int op, const double* p, size_t P, siz
   const double* d_params = nullptr;
   if ((rc = acquire_params(m, p, P * n_p, up, &d_params))) return rc;
   rc = launch_grid(m, op, d_params, P, static_cast<double*>(d_out), ss, N0, N1, row_begin, row_count, layout, s);
-  return release_params_after(m, last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side, rc);
+  rc = release_params_after(m, last_reader_is_callers_stream(m, op, layout, P, N1) ? s : m->side, rc);
+  if (rc == INFLX_OK && !m->sf_words.empty() && s != m->stream) {  // (see sf_done: the stream that finishes the sweep is the caller's)
+    if (!m->sf_done) HIP_TRY(hipEventCreateWithFlags(&m->sf_done, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(m->sf_done, s));
+    m->sf_pending = true;
+  }
+  return rc;
 }
 
 int inflx_sweep_device_timed(inflx_model* m, int op, const double* p, size_t P, size_t n_p, void* d_out, size_t d_out_bytes,

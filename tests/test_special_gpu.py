@@ -301,10 +301,13 @@ def test_special_function_domain_errors_fail_the_call_like_the_reference(gpu_lib
     # device-resident: asynchronous, reports at inflx_synchronize
     ss = np.array([[outside[0], outside[1]], [outside[2], outside[3]]])
     out = torch.empty(n0 * n1 * 6, dtype=torch.float64, device="cuda:0")
-    al.dylib.sweep_device(gpu_lib.OP_COMPLETE, args, out.data_ptr(), out.numel() * 8, ss, n0, n1, stream=torch.cuda.current_stream().cuda_stream)
+    st = torch.cuda.Stream()  # a non-blocking stream of the caller's: the handle waits for ITS sweep on it through an event of its own
+    st.wait_stream(torch.cuda.current_stream())
+    al.dylib.sweep_device(gpu_lib.OP_COMPLETE, args, out.data_ptr(), out.numel() * 8, ss, n0, n1, stream=st.cuda_stream)
     with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
         al.dylib.synchronize()
     al.dylib.synchronize()
+    st.synchronize()
 
     quiet = GeneralisedAL_(art, sf_errors="nan")
     res = quiet.complete_analysis(args, *outside, n0, n1, progress=False)
