@@ -431,6 +431,12 @@ class Compiler:
     #: (D5: 224, on: 0.592 -> 0.519 ms per 4096^2 sweep in round 2.  EGNO: 88, off: with it 0.409 -> 0.422 ms in round 3 --
     #: its quick point stage needs 20 spilled registers to keep three wavefronts per SIMD, or falls back to two.)
     HOIST_MIN_GAIN = 100
+    #: ... and a model below that bar with at least this many quotients by earlier-stage denominators gets them as self-checking
+    #: quotients in its ONE point stage (``hoist_reciprocals="inline"``) -- provided the tile kernel then still holds three wavefronts
+    #: per SIMD (decided on the built object by the criterion of MAX_SCRATCH_FOR_THREE_WAVES, cached).  EGNO: 12 quotients, 604 -> 557 VALU instructions per point
+    #: (SQ counters), 0.419 -> 0.401 ms per 4096^2 sweep and 3.215 -> 3.057 ms per 8 parameter rows in one session, bit-identical
+    #: (profiles/r06_experiments.txt section 7); doc has one such quotient, angular none: unchanged.
+    INLINE_MIN_QUOTIENTS = 6
     #: ``tan_shortcut`` of a default build: off -- eta_parallel is OCML's tan of OCML's atan, like the reference's is libm's
     DEFAULT_TAN_SHORTCUT = 0
     #: ``tan_shortcut`` of the profile-guided build (``regroup="auto"``) unless the caller says otherwise: that build
@@ -695,14 +701,29 @@ class Compiler:
             # comparison unless its numerator is made of earlier-stage values), one by a shared per-point reciprocal 3 + 1
             # and the 5 + 1 of the reciprocal once per group
             text, info = emit(self.staged)
+            self._inline_fallback = None
             if self.quick_point_gain(info) < self.HOIST_MIN_GAIN:
                 text, info = emit(False)
+                if self.staged:
+                    itext, iinfo = emit("inline")
+                    if iinfo.get("inline_quotients", 0) >= self.INLINE_MIN_QUOTIENTS and self._inline_verdict(itext) != "no":
+                        # (the plain form stays at hand: compile() falls back to it when the built kernel spills)
+                        self._inline_fallback = (text, info)
+                        text, info = itext, iinfo
         else:
             text, info = emit(self.hoist_reciprocals)
         value_names = ("V", "v00", "v10", "v11", "g")
         info["regrouped"] = (list(value_names) if self.regroup else []) if isinstance(self.regroup, bool) else [value_names[k] for k in sorted(self.regroup) if k < 5]
         self.stage_info = info
         return text
+
+    def _inline_verdict_path(self, inline_header: str) -> str:
+        return os.path.join(_cache_dir(), hashlib.sha256(("inline-verdict:" + " ".join(self.hipcc_opts) + inline_header).encode()).hexdigest()[:20] + ".inline")
+
+    def _inline_verdict(self, inline_header: str):
+        """"no": this model's self-checking-quotient build lost the third wavefront per SIMD (see compile()); "yes" / None: fine / not built yet."""
+        path = self._inline_verdict_path(inline_header)
+        return open(path).read().strip() if os.path.exists(path) else None
 
     def _hipcc_compile(self, header_text: str):
         kernel_src = os.path.join(_CSRC, "inflx_sweep_kernels.hip")
@@ -776,6 +797,20 @@ class Compiler:
             print("Compiling model...")
         header = self._generate_hip_header()
         cached, header_path, log, code, options, tag = self._hipcc_compile(header)
+        fallback = getattr(self, "_inline_fallback", None)
+        if code == 0 and fallback is not None and self._inline_verdict(header) is None:
+            # the automatic choice of self-checking quotients stands only if the tile kernel keeps three wavefronts per SIMD (the
+            # quotients hold denominator AND reciprocal in registers: EGNO 138 -> 168 VGPRs and 36 B of scratch, measured faster all
+            # the same); a model it would push down to two wavefronts gets the plain point stage instead
+            fits = "-DINFLX_MIN_WAVES=3" in options
+            tmp = self._inline_verdict_path(header) + f".{os.getpid()}.tmp"
+            with open(tmp, "w") as fh:
+                fh.write(("yes" if fits else "no") + "\n")
+            os.replace(tmp, self._inline_verdict_path(header))
+            if not fits:
+                header, self.stage_info = fallback
+                self._inline_fallback = None
+                cached, header_path, log, code, options, tag = self._hipcc_compile(header)
         if code != 0:
             print(log.decode("utf-8", "replace"))
             print(f'Problematic source file located at: "{header_path}"')

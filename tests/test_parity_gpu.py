@@ -917,9 +917,11 @@ def test_hoisted_reciprocal_mode_equals_the_default_on_the_gpu(name, gpu_lib):
     if name == "d5":
         assert info["hoisted_quotients"] >= 20 and info["shared_quotients"] >= 8 and info["shared_reciprocals"] == 4
     # the default (automatic) choice: the quick program (without shared per-point reciprocals) where it saves enough
-    # instructions per point -- D5 yes, the others no
+    # instructions per point -- D5 yes, the others no; of the others, EGNO has enough such quotients (12) to take them as
+    # self-checking ones in its one point stage (round 6, Compiler.INLINE_MIN_QUOTIENTS)
     auto = devlib(name, gpu_lib)[1].stage_info
     assert auto["shared_quotients"] == 0 and auto["hoisted_quotients"] == (info["hoisted_quotients"] if name == "d5" else 0)
+    assert auto["inline_quotients"] == (12 if name == "egno" else 0)
     ss = np.array(spec.extent).reshape(2, 2)
     wide = np.array([[spec.extent[0] - 0.3 * (spec.extent[1] - spec.extent[0]), spec.extent[1]], [spec.extent[2], spec.extent[3]]])
     # the third grid starts exactly at x1 = 0 and x0 = 0 where the models have them in range: structural zeros (a

@@ -129,7 +129,7 @@ def test_fast_mode_is_close_but_not_exact(name):
         # divisions, a quotient by a hoisted or shared reciprocal is one
         start = h.index("void inflx_stage_point_ieee(") if "inflx_stage_point_ieee" in h else h.index("void inflx_stage_point(")
         body = h[start : h.index("}\n", start)]
-        return body.count("/") - body.count(".0/") + body.count("INFLX_DIVH(") + body.count("INFLX_DIVS(")
+        return body.count("/") - body.count(".0/") + body.count("INFLX_DIVH(") + body.count("INFLX_DIVS(") + body.count("INFLX_DIVI(")
 
     if name != "doc":
         assert point_divisions(hdr) < point_divisions(exact_hdr), "fast mode should divide less often per grid point"
@@ -254,8 +254,12 @@ def test_hoisted_reciprocals_are_used_and_change_nothing(name):
     _, auto = header_for(name)
     plain, with_plain = header_for(name, hoist_reciprocals=True)  # without shared per-point reciprocals (the default)
     gain = Compiler.quick_point_gain(plain.stage_info)
-    assert auto == (with_plain if gain >= Compiler.HOIST_MIN_GAIN else without) and "= INFLX_RCPN(" not in with_plain
+    # ... and below that bar: the same quotients checking themselves in the one point stage where there are enough of them (round 6)
+    inline_auto, with_inline = header_for(name, hoist_reciprocals="inline")
+    few = inline_auto.stage_info["inline_quotients"] < Compiler.INLINE_MIN_QUOTIENTS
+    assert auto == (with_plain if gain >= Compiler.HOIST_MIN_GAIN else (without if few else with_inline)) and "= INFLX_RCPN(" not in with_plain
     assert (gain >= Compiler.HOIST_MIN_GAIN) == {"d5": True, "egno": False, "doc": False}[name], gain
+    assert few == {"d5": False, "egno": False, "doc": True}[name]
     # the point stage's square roots take the guarded spelling exactly where the quick stage exists (quick_sqrt=None), or on request
     roots = {"d5": 3, "egno": 4, "doc": 1}[name]
     assert with_h.count("INFLX_SQRT(x)") == 2 and forced.stage_info["quick_square_roots"] == roots
