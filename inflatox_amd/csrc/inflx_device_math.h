@@ -114,10 +114,8 @@ INFLX_FN double inflx_div_by_hoisted_inline(double a, double b, double y) {
   const double q0 = a * y;
   const double r = __builtin_fma(-b, q0, a);
   double q = __builtin_fma(r, y, q0);
-#ifndef INFLX_DIVH_TRUST  // (experiments only: time the hot loop as if every quotient were accepted)
   const bool regular = __builtin_fabs(q) >= 0x1p-400;
   if (__builtin_expect(__builtin_amdgcn_ballot_w64(!regular) != 0, 0)) q = regular ? q : a / b;
-#endif
   return q;
 }
 #else
