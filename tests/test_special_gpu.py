@@ -321,3 +321,9 @@ def test_special_function_domain_errors_fail_the_call_like_the_reference(gpu_lib
     assert quiet.dylib.sf_status() == gpu_lib.SF_EDOM
     with pytest.raises(ValueError):
         GeneralisedAL_(art, sf_errors="abort")
+    # one call, several device handles (two on this GPU): every handle carries the policy, the first failing block reports
+    both = GeneralisedAL_(art, devices=[0, 0])
+    with pytest.raises(gpu_lib.InflatoxSpecialFunctionError):
+        both.complete_analysis(args, *outside, n0, n1, progress=False)
+    res2 = GeneralisedAL_(art, devices=[0, 0], sf_errors="nan").complete_analysis(args, *outside, n0, n1, progress=False)
+    assert all(np.array_equal(a, b, equal_nan=True) for a, b in zip(res, res2))
