@@ -85,7 +85,7 @@ def test_integer_bessel_and_0F1_model_on_the_gpu(gpu_lib):
     model, comp, art = _build(example_models.bessel_0f1, "bessel_0f1", assertions=False, simplify=False)
     al = generalised_al(art)
     args = np.array([1.2, 1.5])
-    n0, n1, ext = 14, 5, (0.4, 9.0, 0.2, 2.9)
+    n0, n1, ext = 10, 4, (0.4, 9.0, 0.2, 2.9)  # (the 30-digit evaluation is what takes the time)
     pts = oracle.grid_points(ext, n0, n1)
     want = special.raw_values_mp(model, comp.symbol_dict, args, pts)
     raw = al.dylib.sweep_host(gpu_lib.OP_RAW, args, np.array([[ext[0], ext[1]], [ext[2], ext[3]]]), n0, n1).reshape(-1, 5)
@@ -111,7 +111,7 @@ def test_real_order_bessel_model_on_the_gpu(gpu_lib):
 
     model, comp, art = _build(example_models.bessel_real, "bessel_real", assertions=False, simplify=False)
     al = generalised_al(art)
-    n0, n1, ext = 11, 4, (0.4, 9.0, 0.2, 2.9)  # (the 30-digit evaluation of the derivatives' Bessel functions is what takes the time)
+    n0, n1, ext = 8, 3, (0.4, 9.0, 0.2, 2.9)  # (the 30-digit evaluation of the derivatives' Bessel functions is what takes the time)
     pts = oracle.grid_points(ext, n0, n1)
     ss = np.array([[ext[0], ext[1]], [ext[2], ext[3]]])
     for nu in (2.6, 3.0):
