@@ -465,6 +465,9 @@ int release_params_after(inflx_model* m, hipStream_t reader, int rc) {
 // bit there.  The reference's GSL error handler prints the reason and panics (src/err.rs:86-103, installed by src/dylib.rs:141-148
 // when USE_GSL = 1): the call does not return.  Here the host reads the words after the sweep.
 void note_sf_word(inflx_model* m, hipModule_t module) {
+  // only a USE_GSL artefact can call the special functions (the printer refuses them otherwise, as the reference's does): every other
+  // model is left without status words, i.e. without any of the bookkeeping below
+  if (!m->use_gsl) return;
   hipDeviceptr_t dptr = nullptr;
   size_t size = 0;
   if (hipModuleGetGlobal(&dptr, &size, module, "INFLX_SF_STATUS") == hipSuccess && size == sizeof(unsigned))
